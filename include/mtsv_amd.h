@@ -1,0 +1,167 @@
+/*
+ * mtsv_amd.h -- C ABI of the MI355X-native mtsv-binner hot path (libmtsv_amd.so).
+ *
+ * Plain C: opaque handles, pointers and sizes only.  A Rust host binds it the way the reference
+ * already binds its only native dependency (extern "C" block + #[repr(C)] mirrors + RAII Drop:
+ * ssw/src/lib.rs:108-154, :26-32); INTEGRATION.md shows the stub.
+ *
+ * Every int-returning function returns 0 on success and a negative MTSV_E_* code otherwise;
+ * mtsv_last_error() returns a thread-local message.  There is NO CPU fallback: a call that needs
+ * the GPU fails with MTSV_E_DEVICE when no gfx950 device / HIP runtime is usable.
+ *
+ * What each entry point replaces in the reference (paths relative to FofanovLab/mtsv_tools):
+ *   mtsv_index_load        io::from_file::<MGIndex>                      src/io.rs:115-123, src/binner.rs:63
+ *   mtsv_index_to_device   FMIndex::new(bwt, less, occ) (borrow -> HBM)  src/binner.rs:64-67
+ *   mtsv_bin_batch         the worker closure: normalise, matching_tax_ids(fwd), revcomp,
+ *                          matching_tax_ids(rev), chain                   src/binner.rs:77-131,
+ *                          MGIndex::matching_tax_ids                      src/index.rs:258-432
+ *   mtsv_hit               Hit {tax_id, gi, offset, edit}                 src/index.rs:30-40
+ *   mtsv_params            matching_tax_ids' scalar arguments             src/index.rs:258-269
+ *                          (defaults: src/bin/mtsv-binner.rs:63-94)
+ *   mtsv_format_results    write_assignments                              src/binner.rs:310-379
+ *   mtsv_index_build*, mtsv_index_write
+ *                          MGIndex::new + io::write_to_file               src/index.rs:491-582, src/io.rs:125-133
+ *   mtsv_batch_*           the same path as mtsv_bin_batch, split so a host can keep read
+ *                          batches resident in HBM and overlap upload / run / download
+ *                          (replaces the bounded queue of vendor/cue/src/lib.rs:45-105)
+ */
+#ifndef MTSV_AMD_H
+#define MTSV_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MTSV_OK 0
+#define MTSV_E_ARG (-1)      /* invalid argument */
+#define MTSV_E_IO (-2)       /* file cannot be opened / read / written */
+#define MTSV_E_FORMAT (-3)   /* MG-index bytes violate the bincode layout or its invariants */
+#define MTSV_E_DEVICE (-4)   /* no usable HIP device, HIP error, or device-side capacity */
+#define MTSV_E_LIMIT (-5)    /* input exceeds a documented limit of the device layout */
+#define MTSV_E_NOMEM (-6)
+
+typedef struct mtsv_index mtsv_index; /* host copy of the MG-index + per-device HBM layout */
+typedef struct mtsv_batch mtsv_batch; /* device workspace for one batch of reads on one GPU */
+
+/* scalar arguments of MGIndex::matching_tax_ids (src/index.rs:258-269) */
+typedef struct {
+    double edit_rate;        /* -e / --edit-rate      0.13  */
+    uint32_t seed_size;      /* --seed-size           18    */
+    uint32_t seed_interval;  /* --seed-interval       15    */
+    double min_seed;         /* --min-seed            0.015 */
+    uint64_t max_hits;       /* --max-hits            2000  */
+    uint64_t tune_max_hits;  /* --tune-max-hits       200   */
+    int64_t max_assignments; /* --max-assignments     -1 = None */
+    int64_t max_candidates;  /* --max-candidates      -1 = None */
+} mtsv_params;
+
+/* one Hit (src/index.rs:30-40) tagged with the read it belongs to and the strand call
+ * (0 = forward, binner.rs:102; 1 = reverse complement, binner.rs:116) that produced it */
+typedef struct {
+    uint64_t read;   /* index of the read inside the batch */
+    uint32_t tax_id;
+    uint32_t gi;
+    uint32_t edit;
+    uint8_t strand;
+    uint8_t _pad[3];
+    uint64_t offset; /* candidate start - bin start (index.rs:416) */
+} mtsv_hit;
+
+/* shape of a loaded index */
+typedef struct {
+    uint64_t n;        /* symbols in `sequences`, including the trailing '$' */
+    uint64_t n_bins;   /* reference sequences (GI records) */
+    uint32_t occ_k;    /* Occ sampling interval of the file */
+    uint64_t sa_s;     /* suffix-array sampling interval of the file */
+    uint64_t file_bytes;
+    uint64_t device_bytes; /* HBM held on the device it was last uploaded to (0 if none) */
+} mtsv_index_info_t;
+
+/* per-stage device time of the last mtsv_batch_run, measured with HIP events on the batch's
+ * own stream, plus the work counters the roofline accounting needs */
+#define MTSV_N_STAGES 8
+typedef struct {
+    float stage_ms[MTSV_N_STAGES]; /* search, thin+scan, expand, locate, coalesce, verify, gather, total */
+    uint64_t n_reads;
+    uint64_t n_seed_slots;  /* seeds searched (both strands) */
+    uint64_t n_seed_hits;   /* located seed hits */
+    uint64_t lf_steps;      /* LF steps walked by k_locate (0 when the full SA is resident) */
+    uint64_t n_candidates;  /* candidates after coalescing + min_seeds filter */
+    uint64_t n_verified;    /* candidates whose window went through the SW prefilter */
+    uint64_t window_bytes;  /* summed window length of those */
+    uint64_t n_hits;        /* hits returned */
+    uint64_t n_passes;      /* >1 when the batch had to be split to fit the hit workspace */
+} mtsv_batch_stats;
+
+const char *mtsv_last_error(void);
+const char *mtsv_version(void);
+void mtsv_params_default(mtsv_params *p);
+
+/* number of visible HIP devices (0 when none / no runtime); never fails */
+int mtsv_device_count(void);
+
+/* ---- MG-index: load / build / write ----------------------------------------------------- */
+int mtsv_index_load(const char *path, mtsv_index **out);
+/* MGIndex::new: entries in database insertion order; sorted by tax_id (stable) like the BTreeMap */
+int mtsv_index_build(uint64_t n_seqs, const uint32_t *tax_ids, const uint32_t *gis,
+                     const uint8_t *const *seqs, const uint64_t *seq_lens, uint32_t occ_k,
+                     uint64_t sa_s, int n_threads, mtsv_index **out);
+/* mtsv-build: FASTA with `SEQID-TAXID` headers (src/util.rs:26-56, src/io.rs:135-150) */
+int mtsv_index_build_fasta(const char *fasta_path, uint32_t occ_k, uint64_t sa_s, int n_threads,
+                           mtsv_index **out);
+int mtsv_index_write(const mtsv_index *ix, const char *path);
+int mtsv_index_info(const mtsv_index *ix, mtsv_index_info_t *info);
+void mtsv_index_free(mtsv_index *ix);
+
+/* Re-pack the FM-index into the HBM layout of DESIGN.md and upload it to `hip_device`.
+ * flags: MTSV_DEV_* below.  Idempotent per device. */
+#define MTSV_DEV_DEFAULT 0u
+#define MTSV_DEV_SAMPLED_SA_ONLY 1u /* keep the file's row-sampled SA only (LF-walk locate) */
+#define MTSV_DEV_NO_KMER_TABLE 2u   /* no seed-suffix interval table */
+int mtsv_index_to_device(mtsv_index *ix, int hip_device, uint32_t flags);
+
+/* ---- the hot path ----------------------------------------------------------------------- */
+/* bases: concatenated raw read bytes (any case, any byte), read_off[n_reads+1].
+ * *hits is ordered by (read, strand, rank order of the reference's candidate loop) and owned by
+ * the caller (mtsv_hits_free). */
+int mtsv_bin_batch(mtsv_index *ix, int hip_device, const uint8_t *bases, const uint64_t *read_off,
+                   uint64_t n_reads, const mtsv_params *params, mtsv_hit **hits, uint64_t *n_hits);
+void mtsv_hits_free(mtsv_hit *hits);
+
+/* The same path with the batch resident in HBM (what bench.py times).  The index must already be
+ * on `hip_device`.  max_hits_ws = seed-hit workspace entries (0 = default). */
+int mtsv_batch_create(mtsv_index *ix, int hip_device, uint64_t max_reads, uint64_t max_bases,
+                      uint64_t max_hits_ws, mtsv_batch **out);
+int mtsv_batch_upload(mtsv_batch *b, const uint8_t *bases, const uint64_t *read_off,
+                      uint64_t n_reads);
+int mtsv_batch_run(mtsv_batch *b, const mtsv_params *params); /* synchronous: returns when done */
+int mtsv_batch_stats_get(const mtsv_batch *b, mtsv_batch_stats *st);
+int mtsv_batch_download(mtsv_batch *b, mtsv_hit **hits, uint64_t *n_hits);
+void mtsv_batch_free(mtsv_batch *b);
+
+/* ---- result lines (host) ---------------------------------------------------------------- */
+/* write_assignments for a whole batch: hits ordered by read; ids = NUL-separated read ids,
+ * id_off[n_reads+1].  Lines are appended to a malloc'd buffer (*out, *out_len), one per read with
+ * >= 1 hit, in read order.  long_format = --output-format long. */
+int mtsv_format_results(const mtsv_hit *hits, uint64_t n_hits, const char *ids,
+                        const uint64_t *id_off, uint64_t n_reads, int long_format, char **out,
+                        uint64_t *out_len);
+void mtsv_free(void *p);
+
+/* ---- synthetic workloads for bench.py / tests (not part of the drop-in) ---- */
+/* i.i.d. ACGT reference of n_taxa x gis_per_taxon sequences of seq_len, 5% of each overwritten by
+ * a 1%-diverged copy from another taxon, 0.1% of positions in N runs; built straight into an index */
+int mtsv_synth_index(uint64_t seed, uint32_t n_taxa, uint32_t gis_per_taxon, uint64_t seq_len,
+                     uint32_t occ_k, uint64_t sa_s, int n_threads, mtsv_index **out);
+/* n_reads reads of read_len sampled from the index text (90%: sub 1%, ins 0.1%, del 0.1%, N 0.2%,
+ * half reverse-complemented; 10% random).  bases must hold n_reads*read_len bytes. */
+int mtsv_synth_reads(const mtsv_index *ix, uint64_t seed, uint64_t n_reads, uint32_t read_len,
+                     uint8_t *bases, uint64_t *read_off);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MTSV_AMD_H */

@@ -1,0 +1,272 @@
+"""ctypes binding of libmtsv_amd.so (include/mtsv_amd.h).  No algorithm lives here."""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def lib_path():
+    return os.path.join(_HERE, "libmtsv_amd.so")
+
+
+class MtsvError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"mtsv error {code}: {msg}")
+        self.code = code
+
+
+E_ARG, E_IO, E_FORMAT, E_DEVICE, E_LIMIT, E_NOMEM = -1, -2, -3, -4, -5, -6
+
+
+class Params(C.Structure):  # mtsv_params
+    _fields_ = [("edit_rate", C.c_double), ("seed_size", C.c_uint32), ("seed_interval", C.c_uint32),
+                ("min_seed", C.c_double), ("max_hits", C.c_uint64), ("tune_max_hits", C.c_uint64),
+                ("max_assignments", C.c_int64), ("max_candidates", C.c_int64)]
+
+
+class IndexInfo(C.Structure):  # mtsv_index_info_t
+    _fields_ = [("n", C.c_uint64), ("n_bins", C.c_uint64), ("occ_k", C.c_uint32),
+                ("sa_s", C.c_uint64), ("file_bytes", C.c_uint64), ("device_bytes", C.c_uint64)]
+
+
+N_STAGES = 8
+STAGE_NAMES = ("search", "thin_scan", "expand", "locate", "coalesce", "verify", "gather", "total")
+
+
+class BatchStats(C.Structure):  # mtsv_batch_stats
+    _fields_ = [("stage_ms", C.c_float * N_STAGES), ("n_reads", C.c_uint64),
+                ("n_seed_slots", C.c_uint64), ("n_seed_hits", C.c_uint64), ("lf_steps", C.c_uint64),
+                ("n_candidates", C.c_uint64), ("n_verified", C.c_uint64),
+                ("window_bytes", C.c_uint64), ("n_hits", C.c_uint64), ("n_passes", C.c_uint64)]
+
+    def as_dict(self):
+        d = {n: int(getattr(self, n)) for n, _ in self._fields_[1:]}
+        d["stage_ms"] = {STAGE_NAMES[i]: float(self.stage_ms[i]) for i in range(N_STAGES)}
+        return d
+
+
+# mtsv_hit: 8 + 4 + 4 + 4 + 1 + 3 pad + 8 = 32 bytes
+HIT_DTYPE = np.dtype({"names": ["read", "tax_id", "gi", "edit", "strand", "offset"],
+                      "formats": ["<u8", "<u4", "<u4", "<u4", "u1", "<u8"],
+                      "offsets": [0, 8, 12, 16, 20, 24], "itemsize": 32})
+
+EXPORTS = [
+    "mtsv_last_error", "mtsv_version", "mtsv_params_default", "mtsv_device_count",
+    "mtsv_index_load", "mtsv_index_build", "mtsv_index_build_fasta", "mtsv_index_write",
+    "mtsv_index_info", "mtsv_index_free", "mtsv_index_to_device", "mtsv_bin_batch",
+    "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run",
+    "mtsv_batch_stats_get", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
+    "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads",
+]
+
+_lib = None
+
+
+def lib():
+    """Load libmtsv_amd.so; fail loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        p = lib_path()
+        if not os.path.exists(p):
+            raise MtsvError(E_DEVICE, f"{p} is missing: run `make -C mtsv_tools_amd/csrc` "
+                                      "(or __graft_entry__.build()); there is no fallback path")
+        L = C.CDLL(p)
+        vp, u64, u32, i32 = C.c_void_p, C.c_uint64, C.c_uint32, C.c_int
+        L.mtsv_last_error.restype = C.c_char_p
+        L.mtsv_version.restype = C.c_char_p
+        L.mtsv_params_default.argtypes = [C.POINTER(Params)]
+        L.mtsv_index_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+        L.mtsv_index_build.argtypes = [u64, vp, vp, vp, vp, u32, u64, i32, C.POINTER(vp)]
+        L.mtsv_index_build_fasta.argtypes = [C.c_char_p, u32, u64, i32, C.POINTER(vp)]
+        L.mtsv_index_write.argtypes = [vp, C.c_char_p]
+        L.mtsv_index_info.argtypes = [vp, C.POINTER(IndexInfo)]
+        L.mtsv_index_free.argtypes = [vp]
+        L.mtsv_index_free.restype = None
+        L.mtsv_index_to_device.argtypes = [vp, i32, u32]
+        L.mtsv_bin_batch.argtypes = [vp, i32, vp, vp, u64, C.POINTER(Params), C.POINTER(vp),
+                                     C.POINTER(u64)]
+        L.mtsv_hits_free.argtypes = [vp]
+        L.mtsv_hits_free.restype = None
+        L.mtsv_batch_create.argtypes = [vp, i32, u64, u64, u64, C.POINTER(vp)]
+        L.mtsv_batch_upload.argtypes = [vp, vp, vp, u64]
+        L.mtsv_batch_run.argtypes = [vp, C.POINTER(Params)]
+        L.mtsv_batch_stats_get.argtypes = [vp, C.POINTER(BatchStats)]
+        L.mtsv_batch_download.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
+        L.mtsv_batch_free.argtypes = [vp]
+        L.mtsv_batch_free.restype = None
+        L.mtsv_format_results.argtypes = [vp, u64, C.c_char_p, vp, u64, i32, C.POINTER(vp),
+                                          C.POINTER(u64)]
+        L.mtsv_free.argtypes = [vp]
+        L.mtsv_free.restype = None
+        L.mtsv_synth_index.argtypes = [u64, u32, u32, u64, u32, u64, i32, C.POINTER(vp)]
+        L.mtsv_synth_reads.argtypes = [vp, u64, u64, u32, vp, vp]
+        _lib = L
+    return _lib
+
+
+def _check(rc):
+    if rc != 0:
+        raise MtsvError(rc, lib().mtsv_last_error().decode(errors="replace"))
+
+
+def version():
+    return lib().mtsv_version().decode()
+
+
+def device_count():
+    return lib().mtsv_device_count()
+
+
+def default_params(**over):
+    p = Params()
+    lib().mtsv_params_default(C.byref(p))
+    for k, v in over.items():
+        setattr(p, k, -1 if v is None else v)
+    return p
+
+
+def _hits_from(ptr, n):
+    try:
+        if n == 0:
+            return np.zeros(0, dtype=HIT_DTYPE)
+        return np.frombuffer(C.string_at(ptr.value, n * HIT_DTYPE.itemsize), dtype=HIT_DTYPE).copy()
+    finally:
+        lib().mtsv_hits_free(ptr)
+
+
+class MGIndex:
+    """Owning handle of an mtsv_index (host MG-index + per-device HBM layout)."""
+
+    def __init__(self, handle):
+        self.h = handle
+
+    @classmethod
+    def load(cls, path):
+        h = C.c_void_p()
+        _check(lib().mtsv_index_load(os.fsencode(path), C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build(cls, entries, occ_k=64, sa_s=32, threads=4):
+        entries = list(entries)
+        n = len(entries)
+        tax = np.array([e[0] for e in entries], dtype=np.uint32)
+        gi = np.array([e[1] for e in entries], dtype=np.uint32)
+        bufs = [C.create_string_buffer(bytes(e[2]), max(len(e[2]), 1)) for e in entries]
+        ptrs = (C.c_void_p * max(n, 1))(*[C.addressof(b) for b in bufs])
+        lens = np.array([len(e[2]) for e in entries], dtype=np.uint64)
+        h = C.c_void_p()
+        _check(lib().mtsv_index_build(n, tax.ctypes.data, gi.ctypes.data, ptrs, lens.ctypes.data,
+                                      occ_k, sa_s, threads, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def build_fasta(cls, path, occ_k=64, sa_s=32, threads=4):
+        h = C.c_void_p()
+        _check(lib().mtsv_index_build_fasta(os.fsencode(path), occ_k, sa_s, threads, C.byref(h)))
+        return cls(h)
+
+    @classmethod
+    def synth(cls, seed, n_taxa, gis_per_taxon, seq_len, occ_k=64, sa_s=32, threads=8):
+        h = C.c_void_p()
+        _check(lib().mtsv_synth_index(seed, n_taxa, gis_per_taxon, seq_len, occ_k, sa_s, threads,
+                                      C.byref(h)))
+        return cls(h)
+
+    def write(self, path):
+        _check(lib().mtsv_index_write(self.h, os.fsencode(path)))
+
+    def info(self):
+        i = IndexInfo()
+        _check(lib().mtsv_index_info(self.h, C.byref(i)))
+        return {n: int(getattr(i, n)) for n, _ in i._fields_}
+
+    def to_device(self, device=0, flags=0):
+        _check(lib().mtsv_index_to_device(self.h, device, flags))
+
+    def bin_batch(self, bases, read_off, params=None, device=0):
+        """mtsv_bin_batch: hits ordered by (read, strand, rank)."""
+        params = params or default_params()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        out, n = C.c_void_p(), C.c_uint64()
+        _check(lib().mtsv_bin_batch(self.h, device, bases.ctypes.data, read_off.ctypes.data,
+                                    len(read_off) - 1, C.byref(params), C.byref(out), C.byref(n)))
+        return _hits_from(out, n.value)
+
+    def close(self):
+        if self.h is not None and _lib is not None:
+            _lib.mtsv_index_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Batch:
+    """Owning handle of an mtsv_batch (HBM-resident read batch + workspace)."""
+
+    def __init__(self, index, device, max_reads, max_bases, max_hits_ws=0):
+        self.index = index
+        self.h = C.c_void_p()
+        _check(lib().mtsv_batch_create(index.h, device, max_reads, max_bases, max_hits_ws,
+                                       C.byref(self.h)))
+
+    def upload(self, bases, read_off):
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        _check(lib().mtsv_batch_upload(self.h, bases.ctypes.data, read_off.ctypes.data,
+                                       len(read_off) - 1))
+
+    def run(self, params=None):
+        params = params or default_params()
+        _check(lib().mtsv_batch_run(self.h, C.byref(params)))
+
+    def stats(self):
+        s = BatchStats()
+        _check(lib().mtsv_batch_stats_get(self.h, C.byref(s)))
+        return s.as_dict()
+
+    def download(self):
+        out, n = C.c_void_p(), C.c_uint64()
+        _check(lib().mtsv_batch_download(self.h, C.byref(out), C.byref(n)))
+        return _hits_from(out, n.value)
+
+    def close(self):
+        if self.h is not None and _lib is not None:
+            _lib.mtsv_batch_free(self.h)
+        self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def format_results(hits, read_ids, long_format=False):
+    """write_assignments over a batch: returns the result lines as one str."""
+    hits = np.ascontiguousarray(hits, dtype=HIT_DTYPE)
+    blob = b"".join(i.encode() + b"\0" for i in read_ids)
+    off = np.zeros(len(read_ids) + 1, dtype=np.uint64)
+    np.cumsum([len(i.encode()) + 1 for i in read_ids], out=off[1:])
+    out, n = C.c_void_p(), C.c_uint64()
+    _check(lib().mtsv_format_results(hits.ctypes.data, len(hits), blob, off.ctypes.data,
+                                     len(read_ids), int(long_format), C.byref(out), C.byref(n)))
+    try:
+        return C.string_at(out.value, n.value).decode()
+    finally:
+        lib().mtsv_free(out)
+
+
+def synth_reads(index, seed, n_reads, read_len):
+    bases = np.empty(n_reads * read_len, dtype=np.uint8)
+    off = np.empty(n_reads + 1, dtype=np.uint64)
+    _check(lib().mtsv_synth_reads(index.h, seed, n_reads, read_len, bases.ctypes.data,
+                                  off.ctypes.data))
+    return bases, off

@@ -1,0 +1,55 @@
+// batch.hpp -- device workspace of one read batch (see batch.hip).
+#pragma once
+#include <vector>
+
+#include "../../include/mtsv_amd.h"
+#include "dev_index.hpp"
+#include "kernels.hpp"
+
+namespace mtsv {
+
+struct Batch {
+    mtsv_index* ix;
+    DeviceIndex* di;
+    hipStream_t stream = nullptr;
+    uint64_t max_reads, max_bases, hit_cap, hits_cap = 0;
+    uint64_t bytes = 0;
+
+    uint8_t* d_bases = nullptr;
+    uint32_t* d_read_off = nullptr;
+    uint32_t *d_seed_lo = nullptr, *d_seed_cnt = nullptr;
+    uint64_t seed_cap = 0;
+    uint32_t *d_strand_hits = nullptr, *d_strand_nseeds = nullptr, *d_strand_off = nullptr, *d_strand_ncand = nullptr,
+             *d_worklist = nullptr, *d_strand_nout = nullptr, *d_out_off = nullptr;
+    uint64_t* d_tile_sums = nullptr;
+    uint64_t* d_counters = nullptr;
+    uint32_t *d_hit_row = nullptr, *d_hit_ref = nullptr, *d_hit_q = nullptr;
+    uint64_t *d_hit_key = nullptr, *d_cand_tmp = nullptr;
+    uint4 *d_cand = nullptr, *d_out = nullptr;
+    DevHit* d_hits = nullptr;
+    uint64_t* h_counters = nullptr;  // pinned
+    hipEvent_t ev[10];
+
+    std::vector<uint32_t> h_read_off;
+    uint32_t max_len = 0;
+    uint64_t n_reads = 0;
+    uint64_t n_hits_total = 0;
+    mtsv_batch_stats stats{};
+
+    Batch(mtsv_index* ix, DeviceIndex* di, uint64_t max_reads, uint64_t max_bases, uint64_t hit_cap);
+    ~Batch();
+    Batch(const Batch&) = delete;
+    Batch& operator=(const Batch&) = delete;
+
+    void upload(const uint8_t* bases, const uint64_t* read_off, uint64_t n);
+    void run(const mtsv_params& p);
+    void download(mtsv_hit** hits, uint64_t* n);
+};
+
+}  // namespace mtsv
+
+struct mtsv_batch {
+    mtsv::Batch impl;
+    template <class... A>
+    explicit mtsv_batch(A&&... a) : impl(std::forward<A>(a)...) {}
+};

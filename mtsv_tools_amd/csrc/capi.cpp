@@ -1,0 +1,416 @@
+// capi.cpp -- the extern "C" boundary declared in include/mtsv_amd.h.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/mtsv_amd.h"
+#include "batch.hpp"
+#include "dev_index.hpp"
+#include "mgindex.hpp"
+
+using namespace mtsv;
+
+static thread_local std::string g_err;
+
+static int fail(const std::exception& e) {
+    g_err = e.what();
+    auto starts = [&](const char* p) { return g_err.rfind(p, 0) == 0; };
+    if (starts("io:")) return MTSV_E_IO;
+    if (starts("format:")) return MTSV_E_FORMAT;
+    if (starts("device:")) return MTSV_E_DEVICE;
+    if (starts("limit:")) return MTSV_E_LIMIT;
+    if (starts("nomem:")) return MTSV_E_NOMEM;
+    if (starts("arg:")) return MTSV_E_ARG;
+    return MTSV_E_DEVICE;
+}
+static int fail_arg(const char* msg) {
+    g_err = std::string("arg: ") + msg;
+    return MTSV_E_ARG;
+}
+#define GUARD(...)                           \
+    try {                                    \
+        __VA_ARGS__;                         \
+        return MTSV_OK;                      \
+    } catch (const std::bad_alloc&) {        \
+        g_err = "nomem: host allocation";    \
+        return MTSV_E_NOMEM;                 \
+    } catch (const std::exception& e) {      \
+        return fail(e);                      \
+    }
+
+namespace {
+struct SplitMix64 {
+    uint64_t s;
+    explicit SplitMix64(uint64_t seed) : s(seed) {}
+    uint64_t next() {
+        uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        return z ^ (z >> 31);
+    }
+    uint64_t below(uint64_t n) { return n ? (uint64_t)(((unsigned __int128)next() * n) >> 64) : 0; }
+    bool chance(double p) { return (next() >> 11) * (1.0 / 9007199254740992.0) < p; }
+};
+inline uint64_t mix(uint64_t a, uint64_t b) { return SplitMix64(a ^ (b * 0xD6E8FEB86659FD93ull + 0x2545F4914F6CDD1Dull)).next(); }
+
+template <class F>
+void par_for(uint64_t n, int threads, F fn) {
+    if (threads < 1) threads = 1;
+    std::vector<std::thread> pool;
+    uint64_t chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; t++) {
+        uint64_t lo = std::min(n, (uint64_t)t * chunk), hi = std::min(n, lo + chunk);
+        if (lo < hi) pool.emplace_back(fn, lo, hi);
+    }
+    for (auto& th : pool) th.join();
+}
+}  // namespace
+
+extern "C" {
+
+const char* mtsv_last_error(void) { return g_err.c_str(); }
+const char* mtsv_version(void) { return "mtsv_tools_amd 0.1.0 (gfx950)"; }
+
+void mtsv_params_default(mtsv_params* p) {  // src/bin/mtsv-binner.rs:63-94
+    p->edit_rate = 0.13;
+    p->seed_size = 18;
+    p->seed_interval = 15;
+    p->min_seed = 0.015;
+    p->max_hits = 2000;
+    p->tune_max_hits = 200;
+    p->max_assignments = -1;
+    p->max_candidates = -1;
+}
+
+int mtsv_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mtsv_index_load(const char* path, mtsv_index** out) {
+    if (!path || !out) return fail_arg("null argument");
+    GUARD({
+        auto ix = std::make_unique<mtsv_index>();
+        load_index(path, ix->host);
+        *out = ix.release();
+    })
+}
+
+int mtsv_index_build(uint64_t n_seqs, const uint32_t* tax_ids, const uint32_t* gis, const uint8_t* const* seqs,
+                     const uint64_t* seq_lens, uint32_t occ_k, uint64_t sa_s, int n_threads, mtsv_index** out) {
+    if (!out || (n_seqs && (!tax_ids || !gis || !seqs || !seq_lens))) return fail_arg("null argument");
+    GUARD({
+        std::vector<SeqEntry> e(n_seqs);
+        for (uint64_t i = 0; i < n_seqs; i++) e[i] = SeqEntry{tax_ids[i], gis[i], seqs[i], seq_lens[i]};
+        auto ix = std::make_unique<mtsv_index>();
+        build_index(std::move(e), occ_k, sa_s, n_threads, ix->host);
+        *out = ix.release();
+    })
+}
+
+int mtsv_index_build_fasta(const char* fasta_path, uint32_t occ_k, uint64_t sa_s, int n_threads, mtsv_index** out) {
+    if (!fasta_path || !out) return fail_arg("null argument");
+    GUARD({
+        auto ix = std::make_unique<mtsv_index>();
+        build_index_from_fasta(fasta_path, occ_k, sa_s, n_threads, ix->host);
+        *out = ix.release();
+    })
+}
+
+int mtsv_index_write(const mtsv_index* ix, const char* path) {
+    if (!ix || !path) return fail_arg("null argument");
+    GUARD({
+        write_index(ix->host, path);
+        const_cast<mtsv_index*>(ix)->host.file_bytes = 0;
+    })
+}
+
+int mtsv_index_info(const mtsv_index* ix, mtsv_index_info_t* info) {
+    if (!ix || !info) return fail_arg("null argument");
+    info->n = ix->host.n();
+    info->n_bins = ix->host.bins.size();
+    info->occ_k = ix->host.k;
+    info->sa_s = ix->host.s;
+    info->file_bytes = ix->host.file_bytes;
+    info->device_bytes = 0;
+    for (auto& kv : ix->dev) info->device_bytes = kv.second->bytes;
+    return MTSV_OK;
+}
+
+void mtsv_index_free(mtsv_index* ix) {
+    if (!ix) return;
+    for (auto& kv : ix->cached_batch) delete kv.second;
+    delete ix;
+}
+
+int mtsv_index_to_device(mtsv_index* ix, int hip_device, uint32_t flags) {
+    if (!ix) return fail_arg("null index");
+    GUARD({
+        std::lock_guard<std::mutex> lk(ix->mu);
+        auto it = ix->dev.find(hip_device);
+        if (it == ix->dev.end() || it->second->flags != flags) {
+            auto cb = ix->cached_batch.find(hip_device);
+            if (cb != ix->cached_batch.end()) {
+                delete cb->second;
+                ix->cached_batch.erase(cb);
+            }
+            if (it != ix->dev.end()) ix->dev.erase(it);
+            ix->dev[hip_device] = upload_index(ix->host, hip_device, flags);
+        }
+    })
+}
+
+static DeviceIndex* device_index(mtsv_index* ix, int dev) {
+    auto it = ix->dev.find(dev);
+    if (it == ix->dev.end()) throw std::runtime_error("arg: index is not resident on device " + std::to_string(dev) + " (call mtsv_index_to_device)");
+    return it->second.get();
+}
+
+int mtsv_batch_create(mtsv_index* ix, int hip_device, uint64_t max_reads, uint64_t max_bases, uint64_t max_hits_ws,
+                      mtsv_batch** out) {
+    if (!ix || !out) return fail_arg("null argument");
+    GUARD({
+        std::lock_guard<std::mutex> lk(ix->mu);
+        *out = new mtsv_batch(ix, device_index(ix, hip_device), max_reads, max_bases, max_hits_ws);
+    })
+}
+
+int mtsv_batch_upload(mtsv_batch* b, const uint8_t* bases, const uint64_t* read_off, uint64_t n_reads) {
+    if (!b || !read_off || (!bases && n_reads && read_off[n_reads] != read_off[0])) return fail_arg("null argument");
+    GUARD(b->impl.upload(bases, read_off, n_reads))
+}
+
+int mtsv_batch_run(mtsv_batch* b, const mtsv_params* params) {
+    if (!b || !params) return fail_arg("null argument");
+    GUARD(b->impl.run(*params))
+}
+
+int mtsv_batch_stats_get(const mtsv_batch* b, mtsv_batch_stats* st) {
+    if (!b || !st) return fail_arg("null argument");
+    *st = b->impl.stats;
+    return MTSV_OK;
+}
+
+int mtsv_batch_download(mtsv_batch* b, mtsv_hit** hits, uint64_t* n_hits) {
+    if (!b || !hits || !n_hits) return fail_arg("null argument");
+    GUARD(b->impl.download(hits, n_hits))
+}
+
+void mtsv_batch_free(mtsv_batch* b) { delete b; }
+
+int mtsv_bin_batch(mtsv_index* ix, int hip_device, const uint8_t* bases, const uint64_t* read_off, uint64_t n_reads,
+                   const mtsv_params* params, mtsv_hit** hits, uint64_t* n_hits) {
+    if (!ix || !read_off || !params || !hits || !n_hits) return fail_arg("null argument");
+    if (hip_device < 0) return fail_arg("hip_device must name a GPU: this library has no CPU path");
+    int rc = mtsv_index_to_device(ix, hip_device, ix->dev.count(hip_device) ? ix->dev[hip_device]->flags : MTSV_DEV_DEFAULT);
+    if (rc != MTSV_OK) return rc;
+    GUARD({
+        std::lock_guard<std::mutex> lk(ix->mu);
+        const uint64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
+        mtsv_batch*& cb = ix->cached_batch[hip_device];
+        if (!cb || cb->impl.max_reads < n_reads || cb->impl.max_bases < nb) {
+            delete cb;
+            cb = nullptr;
+            cb = new mtsv_batch(ix, device_index(ix, hip_device), std::max<uint64_t>(n_reads, 1024),
+                                std::max<uint64_t>(nb, 1 << 16), 0);
+        }
+        cb->impl.upload(bases, read_off, n_reads);
+        cb->impl.run(*params);
+        cb->impl.download(hits, n_hits);
+    })
+}
+
+void mtsv_hits_free(mtsv_hit* hits) { free(hits); }
+void mtsv_free(void* p) { free(p); }
+
+// ---- write_assignments (src/binner.rs:310-379) ------------------------------------------------
+int mtsv_format_results(const mtsv_hit* hits, uint64_t n_hits, const char* ids, const uint64_t* id_off, uint64_t n_reads,
+                        int long_format, char** out, uint64_t* out_len) {
+    if ((!hits && n_hits) || !ids || !id_off || !out || !out_len) return fail_arg("null argument");
+    GUARD({
+        std::string buf;
+        struct Item {
+            uint32_t tax, gi;
+            uint64_t off;
+            uint32_t edit;
+        };
+        std::vector<Item> items;
+        uint64_t i = 0;
+        char num[96];
+        while (i < n_hits) {
+            uint64_t r = hits[i].read;
+            if (r >= n_reads) throw std::runtime_error("arg: hit refers to a read outside the batch");
+            uint64_t j = i;
+            items.clear();
+            for (; j < n_hits && hits[j].read == r; j++) {
+                const mtsv_hit& h = hits[j];
+                bool found = false;
+                for (auto& it : items) {
+                    bool same = long_format ? (it.tax == h.tax_id && it.gi == h.gi && it.off == h.offset) : it.tax == h.tax_id;
+                    if (same) {
+                        if (h.edit < it.edit) it.edit = h.edit;  // smallest edit per key (binner.rs:326-331,358-361)
+                        found = true;
+                        break;
+                    }
+                }
+                if (!found) items.push_back(Item{h.tax_id, h.gi, h.offset, h.edit});
+            }
+            if (j < n_hits && hits[j].read < r) throw std::runtime_error("arg: hits are not ordered by read");
+            if (long_format)
+                std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+                    if (a.tax != b.tax) return a.tax < b.tax;
+                    if (a.gi != b.gi) return a.gi < b.gi;
+                    if (a.off != b.off) return a.off < b.off;
+                    return a.edit < b.edit;
+                });
+            else
+                std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) {
+                    if (a.tax != b.tax) return a.tax < b.tax;
+                    return a.edit < b.edit;
+                });
+            buf.append(ids + id_off[r], strnlen(ids + id_off[r], id_off[r + 1] - id_off[r]));
+            buf.push_back(':');
+            bool first = true;
+            for (auto& it : items) {
+                if (!first) buf.push_back(',');
+                first = false;
+                if (long_format)
+                    snprintf(num, sizeof num, "%u-%u-%llu=%u", it.tax, it.gi, (unsigned long long)it.off, it.edit);
+                else
+                    snprintf(num, sizeof num, "%u=%u", it.tax, it.edit);
+                buf.append(num);
+            }
+            buf.push_back('\n');
+            i = j;
+        }
+        char* o = (char*)malloc(buf.size() + 1);
+        if (!o) throw std::bad_alloc();
+        memcpy(o, buf.data(), buf.size());
+        o[buf.size()] = 0;
+        *out = o;
+        *out_len = buf.size();
+    })
+}
+
+// ---- synthetic workloads -------------------------------------------------------
+
+int mtsv_synth_index(uint64_t seed, uint32_t n_taxa, uint32_t gis_per_taxon, uint64_t seq_len, uint32_t occ_k,
+                     uint64_t sa_s, int n_threads, mtsv_index** out) {
+    if (!out || !n_taxa || !gis_per_taxon || seq_len < 64) return fail_arg("bad synthetic database shape");
+    GUARD({
+        const uint64_t nseq = (uint64_t)n_taxa * gis_per_taxon;
+        std::vector<std::string> seqs(nseq);
+        static const char ACGT[4] = {'A', 'C', 'G', 'T'};
+        par_for(nseq, n_threads, [&](uint64_t lo, uint64_t hi) {
+            for (uint64_t i = lo; i < hi; i++) {
+                SplitMix64 rng(mix(seed, i));
+                std::string& s = seqs[i];
+                s.resize(seq_len);
+                for (uint64_t p = 0; p < seq_len;) {
+                    uint64_t w = rng.next();
+                    for (int k = 0; k < 32 && p < seq_len; k++, p++, w >>= 2) s[p] = ACGT[w & 3];
+                }
+            }
+        });
+        // 5% of every GI: a 1%-diverged copy of a segment of a GI of another taxon
+        SplitMix64 rng(mix(seed, 0xC0FFEE));
+        const uint64_t seg = std::max<uint64_t>(1, seq_len / 20);
+        if (n_taxa > 1)
+            for (uint64_t i = 0; i < nseq; i++) {
+                uint64_t my_tax = i / gis_per_taxon;
+                uint64_t src_tax = rng.below(n_taxa - 1);
+                if (src_tax >= my_tax) src_tax++;
+                uint64_t src = src_tax * gis_per_taxon + rng.below(gis_per_taxon);
+                uint64_t sp = rng.below(seq_len - seg + 1), dp = rng.below(seq_len - seg + 1);
+                for (uint64_t k = 0; k < seg; k++) {
+                    char c = seqs[src][sp + k];
+                    if (rng.chance(0.01)) c = ACGT[rng.below(4)];
+                    seqs[i][dp + k] = c;
+                }
+            }
+        // 0.1% of positions in runs of N of length 10..100
+        for (uint64_t i = 0; i < nseq; i++) {
+            uint64_t target = seq_len / 1000, placed = 0;
+            while (placed < target) {
+                uint64_t len = 10 + rng.below(91);
+                if (len >= seq_len) break;
+                uint64_t at = rng.below(seq_len - len);
+                for (uint64_t k = 0; k < len; k++) seqs[i][at + k] = 'N';
+                placed += len;
+            }
+        }
+        // distinct TaxIDs / GIs
+        std::vector<uint32_t> tax(nseq), gi(nseq);
+        std::vector<uint32_t> taxids;
+        while (taxids.size() < n_taxa) {
+            uint32_t t = (uint32_t)rng.next();
+            if (std::find(taxids.begin(), taxids.end(), t) == taxids.end()) taxids.push_back(t);
+        }
+        for (uint64_t i = 0; i < nseq; i++) {
+            tax[i] = taxids[i / gis_per_taxon];
+            gi[i] = (uint32_t)(mix(seed ^ 0x6D747376ull, i) | 1u) + (uint32_t)i;  // distinct enough; uniqueness not required
+        }
+        std::vector<SeqEntry> e(nseq);
+        for (uint64_t i = 0; i < nseq; i++) e[i] = SeqEntry{tax[i], gi[i], (const uint8_t*)seqs[i].data(), seqs[i].size()};
+        auto ix = std::make_unique<mtsv_index>();
+        build_index(std::move(e), occ_k, sa_s, n_threads, ix->host);
+        *out = ix.release();
+    })
+}
+
+int mtsv_synth_reads(const mtsv_index* ix, uint64_t seed, uint64_t n_reads, uint32_t read_len, uint8_t* bases,
+                     uint64_t* read_off) {
+    if (!ix || !bases || !read_off || read_len == 0) return fail_arg("null argument");
+    const std::vector<uint8_t>& text = ix->host.text;
+    if (text.size() < (uint64_t)read_len * 2 + 16) return fail_arg("index too small for this read length");
+    GUARD({
+        static const uint8_t ACGT[4] = {'A', 'C', 'G', 'T'};
+        int threads = (int)std::max(1u, std::min(32u, std::thread::hardware_concurrency()));
+        const uint64_t span = text.size() - 1 - ((uint64_t)read_len + read_len / 4 + 8);
+        for (uint64_t r = 0; r <= n_reads; r++) read_off[r] = r * read_len;
+        par_for(n_reads, threads, [&](uint64_t lo, uint64_t hi) {
+            std::vector<uint8_t> tmp(read_len);
+            for (uint64_t r = lo; r < hi; r++) {
+                SplitMix64 rng(mix(seed, r));
+                uint8_t* dst = bases + r * read_len;
+                if (rng.chance(0.10)) {  // no origin
+                    for (uint32_t i = 0; i < read_len; i++) dst[i] = ACGT[rng.below(4)];
+                    continue;
+                }
+                uint64_t p = rng.below(span);
+                uint32_t i = 0;
+                while (i < read_len) {
+                    if (rng.chance(0.001)) {  // deletion from the read
+                        p++;
+                        continue;
+                    }
+                    if (rng.chance(0.001)) {  // insertion
+                        tmp[i++] = ACGT[rng.below(4)];
+                        continue;
+                    }
+                    uint8_t c = text[p++];
+                    if (rng.chance(0.01)) c = ACGT[rng.below(4)];
+                    if (rng.chance(0.002)) c = 'N';
+                    tmp[i++] = c;
+                }
+                if (rng.chance(0.5)) {
+                    for (uint32_t k = 0; k < read_len; k++) {
+                        uint8_t c = tmp[read_len - 1 - k];
+                        dst[k] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : c == 'T' ? 'A' : 'N';
+                    }
+                } else {
+                    memcpy(dst, tmp.data(), read_len);
+                }
+            }
+        });
+    })
+}
+
+}  // extern "C"

@@ -1,0 +1,61 @@
+// kernels.hpp -- launch interface of the hot-path kernels (kernels.hip).
+#pragma once
+#include <algorithm>
+
+#include "dev_layout.hpp"
+
+namespace mtsv {
+
+struct DevHit {  // byte-identical to mtsv_hit (include/mtsv_amd.h)
+    uint64_t read;
+    uint32_t tax_id;
+    uint32_t gi;
+    uint32_t edit;
+    uint8_t strand;
+    uint8_t pad[3];
+    uint64_t offset;
+};
+static_assert(sizeof(DevHit) == 32, "DevHit must match mtsv_hit");
+
+struct VerifyArgs {
+    const uint8_t* bases;
+    const uint32_t* read_off;
+    uint32_t r0;
+    double edit_rate;
+    int64_t max_candidates;
+    int64_t max_assignments;
+    const uint32_t* strand_off;
+    const uint32_t* strand_ncand;
+    const uint4* cand;
+    const uint32_t* worklist;
+    const uint32_t* wl_count;
+    uint4* out;            // per-strand hit segments: (tax_id, gi, offset, edit)
+    uint32_t* strand_nout;
+    unsigned long long* n_verified;
+    unsigned long long* window_bytes;
+};
+
+constexpr uint32_t kMaxReadLen = 256;  // 4 read rows per lane in k_verify
+
+void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
+                   uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt);
+void launch_thin(hipStream_t s, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, uint32_t max_ns, uint32_t K,
+                 uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* strand_hits,
+                 uint32_t* strand_nseeds);
+// out has n+1 entries (out[n] = total); tile_sums needs scan_tiles(n) entries
+void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_sums, uint64_t* total, uint32_t* out);
+uint32_t scan_tiles(uint32_t n);
+void launch_expand(hipStream_t s, const DevIndexView& ix, uint32_t n_strands, uint32_t max_ns, uint32_t G,
+                   const uint32_t* seed_lo, const uint32_t* seed_cnt, const uint32_t* strand_off, uint32_t* hit_row,
+                   uint32_t* hit_ref, uint32_t* hit_q);
+void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_host, const uint32_t* total_hits_dev,
+                   const uint32_t* hit_row, uint32_t* hit_ref, unsigned long long* lf_steps);
+void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,
+                     double edit_rate, double min_seed, const uint32_t* strand_off, const uint32_t* strand_nseeds,
+                     const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key, uint64_t* cand_tmp, uint4* cand,
+                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, unsigned long long* n_cand_total);
+void launch_verify(hipStream_t s, const DevIndexView& ix, const VerifyArgs& a, uint32_t n_strands);
+void launch_gather(hipStream_t s, uint32_t n_strands, uint32_t r0, const uint32_t* strand_off, const uint32_t* strand_nout,
+                   const uint32_t* out_off, const uint4* out, DevHit* hits, uint64_t hits_base);
+
+}  // namespace mtsv
