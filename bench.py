@@ -1,0 +1,239 @@
+#!/usr/bin/env python3
+"""bench.py -- reads/s of the mtsv-binner hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the whole hot path (seed search -> locate -> coalesce -> SW + edit verify
+-> hit gather) over one batch of synthetic reads that is already resident in HBM; the index is
+replicated per GPU and reads shard across ranks with no collective on the data path (weak
+scaling: every rank processes its own batch of the same size).  Rank 0 prints ONE JSON line.
+
+Workloads (BASELINE.json configs; generators of SURVEY.md 8(d), seeds fixed):
+    config1  1M x 150 bp reads vs "1 GB MG-index"  (n = 2.76e8 symbols, 256 taxa x 4 GIs x 270 kb)
+    config0  10k x 100 bp reads vs "1 MB MG-index" (n = 2.8e5)  -- plumbing / quick check
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+WORKLOADS = {
+    # name: (n_taxa, gis_per_taxon, seq_len, n_reads, read_len, description)
+    "config0": (8, 2, 17500, 10_000, 100, "10k x 100bp reads vs 1MB MG-index (n=2.8e5)"),
+    "config1": (256, 4, 270_000, 1_000_000, 150, "1M x 150bp reads vs 1GB MG-index (n=2.76e8)"),
+    "quarter": (64, 4, 270_000, 1_000_000, 150, "1M x 150bp reads vs 250MB MG-index (n=6.9e7)"),
+}
+SEED_DB = 0x6D747376
+PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def algorithmic_bytes(ctr, n_reads):
+    """bytes = 64*(2X+S) + 8H + W + L + 24R, per read, split per stage."""
+    per = {k: ctr[k] / n_reads for k in ("X", "S", "H", "W", "R", "Lsum")}
+    stage = {
+        "search": 64.0 * 2 * per["X"] + per["Lsum"],
+        "locate": 64.0 * per["S"] + 8.0 * per["H"],
+        "verify": per["W"],
+        "gather": 24.0 * per["R"],
+    }
+    stage["total"] = sum(stage.values())
+    return stage, per
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("MTSV_BENCH_WORKLOAD", "config1"))
+    ap.add_argument("--reads", type=int, default=0, help="override reads per GPU per step")
+    ap.add_argument("--cpu-sample", type=int, default=20000, help="reads timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dev-flags", type=int, default=0, help="MTSV_DEV_* flags (1: sampled SA only, 2: no k-mer table)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N")
+        args.gpus = world
+
+    import torch
+    import torch.distributed as dist
+
+    import mtsv_tools_amd as M
+
+    if not torch.cuda.is_available() or M.device_count() < 1:
+        sys.exit("bench.py needs a HIP device: libmtsv_amd has no CPU path")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_taxa, gis, seq_len, n_reads, read_len, desc = WORKLOADS[args.workload]
+    if args.reads:
+        n_reads = args.reads
+    idx_path = f"/tmp/mtsv_bench_{args.workload}.idx"
+    ncpu = os.cpu_count() or 8
+    build_threads = max(4, min(32, ncpu // max(1, world) if world > 1 else ncpu))
+
+    # ---- index: rank 0 builds + writes the MG-index file, every rank loads it (drop-in format) ----
+    t0 = time.time()
+    if rank == 0:
+        ixb = M.MGIndex.synth(SEED_DB, n_taxa, gis, seq_len, threads=min(32, ncpu))
+        ixb.write(idx_path)
+        ixb.close()
+    t_build = time.time() - t0
+    barrier()
+    t0 = time.time()
+    ix = M.MGIndex.load(idx_path)
+    t_load = time.time() - t0
+    t0 = time.time()
+    ix.to_device(local_rank, args.dev_flags)
+    t_upload = time.time() - t0
+    info = ix.info()
+
+    # ---- reads: each rank its own shard (different seed), resident in HBM before timing ----
+    bases, off = M.synth_reads(ix, seed=1000 + rank, n_reads=n_reads, read_len=read_len)
+    params = M.default_params()
+    batch = M.Batch(ix, local_rank, n_reads, len(bases))
+    t0 = time.time()
+    batch.upload(bases, off)
+    t_h2d = time.time() - t0
+
+    for _ in range(args.warmup):
+        batch.run(params)
+    barrier()
+    stage_acc = None
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.run(params)
+        st = batch.stats()
+        if stage_acc is None:
+            stage_acc = dict(st["stage_ms"])
+        else:
+            for k, v in st["stage_ms"].items():
+                stage_acc[k] += v
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    st = batch.stats()
+    hits = batch.download()
+    t0 = time.time()
+    batch_pcie = M.Batch(ix, local_rank, n_reads, len(bases)) if rank == 0 else None
+    pcie_rate = None
+    if batch_pcie is not None:
+        t0 = time.perf_counter()
+        batch_pcie.upload(bases, off)
+        batch_pcie.run(params)
+        batch_pcie.download()
+        pcie_rate = n_reads / (time.perf_counter() - t0)
+        batch_pcie.close()
+
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    value = n_reads * args.steps * world / elapsed
+    stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
+
+    # ---- CPU baseline + algorithmic-byte counters from the oracle on a bounded sample ----
+    cpu = None
+    ctr_per = None
+    parity = "not checked"
+    stage_bytes = None
+    if not args.no_cpu_baseline:
+        from oracle import oracle as O
+        ns = min(args.cpu_sample, n_reads)
+        oix = O.Index.read(idx_path)
+        cores = min(ncpu, 64)
+        t0 = time.perf_counter()
+        ohits, ctr = oix.bin_batch(bases[: ns * read_len], off[: ns + 1], O.default_params(), threads=cores)
+        dt = time.perf_counter() - t0
+        cpu = {"value": ns / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+               "sample": f"first {ns} reads of rank 0's batch, oracle/libmtsv_oracle.so (reference layout: byte BWT, "
+                         f"Occ k=64, SA s=32, emulated striped SW, full-matrix edit DP), {cores} OpenMP threads, {dt:.1f} s"}
+        stage_bytes, ctr_per = algorithmic_bytes(ctr, ns)
+        g = hits[hits["read"] < ns]
+        same = len(g) == len(ohits) and all(np.array_equal(g[f], ohits[f]) for f in
+                                            ("read", "tax_id", "gi", "edit", "strand", "offset"))
+        parity = f"{'identical' if same else 'MISMATCH'} on {ns} sampled reads ({len(ohits)} hits)"
+
+    # ---- roofline of the dominant kernel ----
+    kernel_stage = {"search": "k_search", "locate": "k_locate", "verify": "k_verify", "coalesce": "k_coalesce",
+                    "expand": "k_expand", "thin_scan": "k_thin+scan", "gather": "scan+k_gather"}
+    dom = max((k for k in stage_ms if k != "total"), key=lambda k: stage_ms[k])
+    roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "kernel": kernel_stage.get(dom, dom), "kernel_ms": stage_ms[dom]}
+    if stage_bytes is not None:
+        # expand carries the locate bytes when the full SA is resident (k_locate does not run)
+        key = dom
+        if dom == "expand":
+            key = "locate"
+        if dom == "coalesce":
+            key = None
+        if key in stage_bytes:
+            a = stage_bytes[key] * n_reads / (stage_ms[dom] * 1e-3) / 1e9
+            roof["achieved"] = a
+            roof["frac"] = a / PEAK_HBM_GBS
+            roof["algorithmic_bytes_per_read"] = stage_bytes[key]
+        pipe = stage_bytes["total"] * n_reads / (stage_ms["total"] * 1e-3) / 1e9
+        roof["pipeline"] = {"algorithmic_bytes_per_read": stage_bytes["total"], "achieved": pipe,
+                            "frac": pipe / PEAK_HBM_GBS, "ms": stage_ms["total"]}
+
+    out = {
+        "metric": "reads/sec (whole node), 150bp reads vs MG-index",
+        "value": value,
+        "unit": "reads/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u32/i16",
+        "data": "synthetic",
+        "config": {"workload": f"{args.workload}: {desc}", "reads_per_gpu_per_step": n_reads, "read_len": read_len,
+                   "index_symbols": info["n"], "index_file_bytes": os.path.getsize(idx_path),
+                   "index_hbm_bytes": info["device_bytes"], "dev_flags": args.dev_flags,
+                   "parallelism": f"reads sharded x{world}, index replicated, no collective"},
+        "roofline": roof,
+        "cpu_baseline": cpu,
+        "stage_ms": stage_ms,
+        "counters_per_read": ctr_per,
+        "device_counters": {k: st[k] for k in ("n_seed_slots", "n_seed_hits", "lf_steps", "n_candidates",
+                                                "n_verified", "window_bytes", "n_hits", "n_passes")},
+        "parity": parity,
+        "pcie_inclusive_reads_per_s": pcie_rate,
+        "setup_s": {"index_build": t_build, "index_load": t_load, "index_pack_upload_accel": t_upload,
+                    "reads_h2d": t_h2d},
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -39,7 +39,6 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_strand_nseeds, ns, &bytes);
     dev_alloc(&d_strand_off, ns + 1, &bytes);
     dev_alloc(&d_strand_ncand, ns, &bytes);
-    dev_alloc(&d_worklist, ns, &bytes);
     dev_alloc(&d_strand_nout, ns + 1, &bytes);
     dev_alloc(&d_out_off, ns + 1, &bytes);
     dev_alloc(&d_tile_sums, (uint64_t)scan_tiles((uint32_t)ns) + 1, &bytes);
@@ -51,6 +50,11 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_cand_tmp, 2 * hit_cap, &bytes);
     dev_alloc(&d_cand, hit_cap, &bytes);
     dev_alloc(&d_out, hit_cap, &bytes);
+    dev_alloc(&d_cand_next, hit_cap, &bytes);
+    dev_alloc(&d_cand_rs, hit_cap, &bytes);
+    dev_alloc(&d_cand_status, hit_cap, &bytes);
+    dev_alloc(&d_worklist, hit_cap, &bytes);
+    dev_alloc(&d_worklist2, hit_cap, &bytes);
     dev_alloc(&d_hits, hits_cap, &bytes);
     HIP_CHECK(hipHostMalloc((void**)&h_counters, 8 * sizeof(uint64_t)));
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
@@ -63,7 +67,7 @@ Batch::~Batch() {
                     (void*)d_strand_nseeds, (void*)d_strand_off, (void*)d_strand_ncand, (void*)d_worklist,
                     (void*)d_strand_nout, (void*)d_out_off, (void*)d_tile_sums, (void*)d_counters, (void*)d_hit_row,
                     (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand, (void*)d_out,
-                    (void*)d_hits})
+                    (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_worklist2})
         (void)hipFree(p);
     (void)hipHostFree(h_counters);
     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -161,29 +165,59 @@ void Batch::run(const mtsv_params& p) {
                           (unsigned long long*)(d_counters + 2));
         HIP_CHECK(hipEventRecord(ev[4], stream));
         // ---- candidates ----
+        // counters: [1] lo = round-0 worklist count, [7] lo/hi = ping-pong counts of later rounds
         HIP_CHECK(hipMemsetAsync(d_counters + 1, 0, 8, stream));
-        launch_coalesce(stream, v, d_read_off, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, d_strand_off, d_strand_nseeds,
-                        d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_strand_ncand, d_worklist,
-                        (uint32_t*)(d_counters + 1), (unsigned long long*)(d_counters + 3));
+        HIP_CHECK(hipMemsetAsync(d_counters + 7, 0, 8, stream));
+        launch_coalesce(stream, v, d_read_off, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, p.max_candidates, d_strand_off,
+                        d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next, d_cand_rs,
+                        d_cand_status, d_strand_ncand, d_worklist, (uint32_t*)(d_counters + 1),
+                        (unsigned long long*)(d_counters + 3));
         HIP_CHECK(hipEventRecord(ev[5], stream));
-        // ---- verify ----
-        VerifyArgs a;
-        a.bases = d_bases;
-        a.read_off = d_read_off;
-        a.r0 = (uint32_t)r0;
-        a.edit_rate = p.edit_rate;
-        a.max_candidates = p.max_candidates;
-        a.max_assignments = p.max_assignments;
-        a.strand_off = d_strand_off;
-        a.strand_ncand = d_strand_ncand;
-        a.cand = d_cand;
-        a.worklist = d_worklist;
-        a.wl_count = (const uint32_t*)(d_counters + 1);
-        a.out = d_out;
-        a.strand_nout = d_strand_nout;
-        a.n_verified = (unsigned long long*)(d_counters + 4);
-        a.window_bytes = (unsigned long long*)(d_counters + 5);
-        launch_verify(stream, v, a, nstr);
+        // ---- verify: rounds over the same-TaxId chains ----
+        {
+            EvalArgs a;
+            a.bases = d_bases;
+            a.read_off = d_read_off;
+            a.r0 = (uint32_t)r0;
+            a.edit_rate = p.edit_rate;
+            a.max_candidates = p.max_candidates;
+            a.strand_off = d_strand_off;
+            a.cand = d_cand;
+            a.cand_next = d_cand_next;
+            a.cand_rs = d_cand_rs;
+            a.cand_status = d_cand_status;
+            a.out = d_out;
+            a.n_verified = (unsigned long long*)(d_counters + 4);
+            a.window_bytes = (unsigned long long*)(d_counters + 5);
+            uint32_t* cnt_a = (uint32_t*)(d_counters + 1);      // round 0 list
+            uint32_t* cnt_b = (uint32_t*)(d_counters + 7);      // next list
+            uint32_t* cnt_c = (uint32_t*)(d_counters + 7) + 1;  // list after that
+            uint32_t *cur = d_worklist, *nxt = d_worklist2, *cur_cnt = cnt_a, *nxt_cnt = cnt_b;
+            uint64_t upper = total_hits;  // candidates <= seed hits
+            for (uint32_t round = 0;; round++) {
+                a.worklist = cur;
+                a.wl_count = cur_cnt;
+                a.worklist_next = nxt;
+                a.wl_next_count = nxt_cnt;
+                launch_evaluate(stream, v, a, upper, max_len);
+                HIP_CHECK(hipMemcpyAsync(h_counters, nxt_cnt, 4, hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                const uint32_t n_next = *(const uint32_t*)h_counters;
+                stats.n_rounds = round + 1;
+                if (n_next == 0) break;
+                upper = n_next;
+                // rotate: next becomes current; the spare count slot is cleared for the round after
+                uint32_t* spare_cnt = (nxt_cnt == cnt_b) ? cnt_c : cnt_b;
+                HIP_CHECK(hipMemsetAsync(spare_cnt, 0, 4, stream));
+                uint32_t* spare_list = (nxt == d_worklist2) ? d_worklist : d_worklist2;
+                cur = nxt;
+                cur_cnt = nxt_cnt;
+                nxt = spare_list;
+                nxt_cnt = spare_cnt;
+            }
+            launch_resolve(stream, nstr, p.max_candidates, p.max_assignments, d_strand_off, d_strand_ncand, d_cand_status,
+                           d_out, d_strand_nout);
+        }
         HIP_CHECK(hipEventRecord(ev[6], stream));
         // ---- gather ----
         launch_scan(stream, d_strand_nout, nstr, d_tile_sums, d_counters + 6, d_out_off);

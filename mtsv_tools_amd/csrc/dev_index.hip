@@ -64,7 +64,7 @@ __global__ void k_expand_sa(DevIndexView ix, uint32_t n_samples, uint32_t* __res
         LoadedBlock b = load_block(ix.blocks, blk);
         uint32_t c = block_code(b, off);
         if (c == kCodeSentinel) break;  // this row is the suffix at text position 0
-        row = ix.C[c] + block_rank(b, c, blk, off, ix.sentinel_row);
+        row = less_of(ix, c) + block_rank(b, c, blk, off, ix.sentinel_row);
         v -= 1;
         if (row % ix.sa_s == 0) break;  // owned by another lane
         sa_full[row] = v;
@@ -75,8 +75,8 @@ __global__ void k_expand_sa(DevIndexView ix, uint32_t n_samples, uint32_t* __res
 __global__ void k_kmer_level1(DevIndexView ix, uint2* __restrict__ tab) {
     uint32_t a = threadIdx.x;
     if (a >= 4) return;
-    uint32_t lo = ix.C[a] + dev_rank(ix, a, 0);
-    uint32_t hi = ix.C[a] + dev_rank(ix, a, ix.n);
+    uint32_t lo = less_of(ix, a) + dev_rank(ix, a, 0);
+    uint32_t hi = less_of(ix, a) + dev_rank(ix, a, ix.n);
     tab[a] = make_uint2(lo, hi);
 }
 
@@ -92,12 +92,12 @@ __global__ void k_kmer_level(DevIndexView ix, const uint2* __restrict__ prev, ui
     if (iv.x < iv.y) {
         uint32_t b0 = iv.x >> kBlockShift, b1 = iv.y >> kBlockShift;
         LoadedBlock B0 = load_block(ix.blocks, b0);
-        lo = ix.C[a] + block_rank(B0, a, b0, iv.x & (kBlockRows - 1), ix.sentinel_row);
+        lo = less_of(ix, a) + block_rank(B0, a, b0, iv.x & (kBlockRows - 1), ix.sentinel_row);
         if (b1 == b0) {
-            hi = ix.C[a] + block_rank(B0, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
+            hi = less_of(ix, a) + block_rank(B0, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
         } else {
             LoadedBlock B1 = load_block(ix.blocks, b1);
-            hi = ix.C[a] + block_rank(B1, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
+            hi = less_of(ix, a) + block_rank(B1, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
         }
     }
     cur[t] = make_uint2(lo, hi);

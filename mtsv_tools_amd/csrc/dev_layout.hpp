@@ -86,11 +86,13 @@ __device__ inline uint64_t u64_of(uint32_t lo, uint32_t hi) { return ((uint64_t)
 
 // symbol code stored at in-block offset off (0..127)
 __device__ inline uint32_t block_code(const LoadedBlock& b, uint32_t off) {
-    uint32_t w = off >> 5, sh = off & 31;
-    uint32_t a0 = (w == 0 ? b.q0.x : w == 1 ? b.q0.y : w == 2 ? b.q0.z : b.q0.w) >> sh;
-    uint32_t a1 = (w == 0 ? b.q1.x : w == 1 ? b.q1.y : w == 2 ? b.q1.z : b.q1.w) >> sh;
-    uint32_t a2 = (w == 0 ? b.q2.x : w == 1 ? b.q2.y : w == 2 ? b.q2.z : b.q2.w) >> sh;
-    return (a0 & 1) | ((a1 & 1) << 1) | ((a2 & 1) << 2);
+    // 64-bit select + shift: keeps the block in registers (indexing its words would go to scratch)
+    bool hi = off & 64;
+    uint32_t sh = off & 63;
+    uint64_t w0 = hi ? u64_of(b.q0.z, b.q0.w) : u64_of(b.q0.x, b.q0.y);
+    uint64_t w1 = hi ? u64_of(b.q1.z, b.q1.w) : u64_of(b.q1.x, b.q1.y);
+    uint64_t w2 = hi ? u64_of(b.q2.z, b.q2.w) : u64_of(b.q2.x, b.q2.y);
+    return (uint32_t)((w0 >> sh) & 1) | ((uint32_t)((w1 >> sh) & 1) << 1) | ((uint32_t)((w2 >> sh) & 1) << 2);
 }
 
 // #rows p < pos with bwt[p] == a, for pos = blk*128 + off, a in 0..4 (exclusive rank; bio's
@@ -112,6 +114,11 @@ __device__ inline uint32_t block_rank(const LoadedBlock& b, uint32_t a, uint32_t
         base = before - (b.h.x + b.h.y + b.h.z + b.h.w) - (before > sentinel_row ? 1u : 0u);
     }
     return base + __popcll(ma & maskA) + __popcll(mb & maskB);
+}
+
+// less[] of symbol code a without dynamic indexing of the by-value view (that would spill C[] to scratch)
+__device__ inline uint32_t less_of(const DevIndexView& ix, uint32_t a) {
+    return a == 0 ? ix.C[0] : a == 1 ? ix.C[1] : a == 2 ? ix.C[2] : a == 3 ? ix.C[3] : ix.C[4];
 }
 
 __device__ inline uint32_t dev_rank(const DevIndexView& ix, uint32_t a, uint32_t pos) {

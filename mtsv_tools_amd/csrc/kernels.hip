@@ -8,9 +8,9 @@
 //   k_expand    lane per strand: SA rows of every kept seed (Interval::occ)       index.rs:347-352
 //   k_locate    lane per seed hit with wavefront refill: SampledSuffixArray::get  index.rs:347
 //   k_coalesce  wavefront per strand: sort, coalesce_seed_sites, min_seeds, rank  index.rs:358-369,435-487
-//   k_verify    wavefront per strand with candidates: SW prefilter + edit
-//               distance + the ordered selection loop                             index.rs:375-431,
-//                                                                                 ssw.c:123-328, align.rs:28-85
+//   k_evaluate  16-lane group per candidate: SW prefilter + edit distance         index.rs:401-410,
+//               (rounds follow the same-TaxId chains of the ordered loop)         ssw.c:123-328, align.rs:28-85
+//   k_resolve   lane per strand: cut-offs and rank order of the selection loop    index.rs:384-428
 //   scan + k_gather  compact per-strand hits into (read, strand, rank) order      binner.rs:128
 //
 // All arithmetic is integer; positions are u32 (n < 2^32).  No MFMA: the path is rank queries and
@@ -80,13 +80,13 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
             uint32_t a = strand_code(read, L, strand, off + (uint32_t)i);
             uint32_t bl = lo >> kBlockShift, bh = hi >> kBlockShift;
             LoadedBlock B0 = load_block(ix.blocks, bl);
-            uint32_t nlo = ix.C[a] + block_rank(B0, a, bl, lo & (kBlockRows - 1), ix.sentinel_row);
+            uint32_t nlo = less_of(ix, a) + block_rank(B0, a, bl, lo & (kBlockRows - 1), ix.sentinel_row);
             uint32_t nhi;
             if (bh == bl) {
-                nhi = ix.C[a] + block_rank(B0, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
+                nhi = less_of(ix, a) + block_rank(B0, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
             } else {
                 LoadedBlock B1 = load_block(ix.blocks, bh);
-                nhi = ix.C[a] + block_rank(B1, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
+                nhi = less_of(ix, a) + block_rank(B1, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
             }
             lo = nlo;
             hi = nhi;
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void k_locate(DevIndexView ix, const uint32_t*
                         hit_ref[idx] = steps;
                         active = false;
                     } else {
-                        row = ix.C[c] + block_rank(b, c, blk, off, ix.sentinel_row);
+                        row = less_of(ix, c) + block_rank(b, c, blk, off, ix.sentinel_row);
                         steps++;
                         my_steps++;
                         if (steps > ix.n) {  // only a corrupt index can cycle without a sampled row
@@ -417,17 +417,25 @@ __device__ void global_bitonic_sort(uint64_t* keys, uint32_t n) {
 
 __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_t* __restrict__ read_off, uint32_t r0,
                                                   uint32_t n_strands, double edit_rate, double min_seed,
-                                                  const uint32_t* __restrict__ strand_off,
+                                                  int64_t max_candidates, const uint32_t* __restrict__ strand_off,
                                                   const uint32_t* __restrict__ strand_nseeds,
                                                   const uint32_t* __restrict__ hit_ref,
                                                   const uint32_t* __restrict__ hit_q, uint64_t* __restrict__ hit_key,
                                                   uint64_t* __restrict__ cand_tmp, uint4* __restrict__ cand,
+                                                  uint32_t* __restrict__ cand_next, uint32_t* __restrict__ cand_rs,
+                                                  uint32_t* __restrict__ cand_status,
                                                   uint32_t* __restrict__ strand_ncand,
                                                   uint32_t* __restrict__ worklist, uint32_t* __restrict__ wl_count,
                                                   unsigned long long* __restrict__ n_cand_total) {
+    __shared__ uint32_t pend_all[256 / kWave][kWave];
+    uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
+    const uint32_t maxc = max_candidates < 0 ? 0xffffffffu
+                                             : (max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)max_candidates);
     const uint32_t lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
+    uint32_t pend = 0;  // work items buffered in pend_buf (wave-uniform)
+    unsigned long long cand_sum = 0;
     for (uint32_t rs = wave; rs < n_strands; rs += n_waves) {
         const uint32_t o = strand_off[rs];
         const uint32_t nh = __builtin_amdgcn_readfirstlane(strand_off[rs + 1] - o);
@@ -479,7 +487,36 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
                 uint32_t nj = __builtin_amdgcn_readlane(mn, j);
                 rank += (nj > mn) || (nj == mn && j < lane);
             }
-            if (lane < nc) cand[o + rank] = make_uint4(ms, me, mb, mn);
+            // same-TaxID chain in rank order: a candidate is verified only after every earlier candidate
+            // of its TaxID has failed (index.rs:393), so only the first of each TaxID starts as work
+            uint32_t tax = lane < nc ? ix.bins[mb].tax_id : 0;
+            uint32_t nxt = 0xffffffffu;
+            bool first = lane < nc;
+            for (uint32_t j = 0; j < nc; j++) {
+                uint32_t tj = __builtin_amdgcn_readlane(tax, j), rj = __builtin_amdgcn_readlane(rank, j);
+                if (tj == tax && rj > rank && rj < nxt) nxt = rj;
+                if (tj == tax && rj < rank) first = false;
+            }
+            if (lane < nc) {
+                cand[o + rank] = make_uint4(ms, me, mb, mn);
+                cand_next[o + rank] = nxt;
+                cand_rs[o + rank] = rs;
+                cand_status[o + rank] = 0;
+            }
+            {
+                bool emit = first && rank < maxc;
+                unsigned long long em = __ballot(emit);
+                uint32_t m = __popcll(em);
+                if (pend + m > kWave) {  // flush the buffered items with one atomic
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(wl_count, pend);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (lane < pend) worklist[base + lane] = pend_buf[lane];
+                    pend = 0;
+                }
+                if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = o + rank;
+                pend += m;
+            }
         } else {
             // ---- segments longer than a wavefront: sort in L2-resident scratch ----
             uint64_t* keys = hit_key + o;
@@ -540,28 +577,60 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
                 uint32_t src = (uint32_t)gload(keys + i);
                 uint64_t se = gload(ct + 2ull * src), bn = gload(ct + 2ull * src + 1);
                 cand[o + i] = make_uint4((uint32_t)se, (uint32_t)(se >> 32), (uint32_t)bn, (uint32_t)(bn >> 32));
+                cand_rs[o + i] = rs;
+                cand_status[o + i] = 0;
+                gstore(keys + i, ((uint64_t)ix.bins[(uint32_t)bn].tax_id << 32) | i);  // (TaxId, rank)
+            }
+            wave_mem_sync();
+            global_bitonic_sort(keys, nc);
+            for (uint32_t base = 0; base < nc; base += kWave) {
+                uint32_t p = base + lane;
+                bool emit = false;
+                uint32_t rk = 0;
+                if (p < nc) {
+                    uint64_t k0 = gload(keys + p);
+                    uint64_t kn = p + 1 < nc ? gload(keys + p + 1) : ~0ull;
+                    uint64_t kp = p > 0 ? gload(keys + p - 1) : ~0ull;
+                    rk = (uint32_t)k0;
+                    cand_next[o + rk] = (kn >> 32) == (k0 >> 32) ? (uint32_t)kn : 0xffffffffu;
+                    emit = (p == 0 || (kp >> 32) != (k0 >> 32)) && rk < maxc;
+                }
+                unsigned long long em = __ballot(emit);
+                if (em) {
+                    uint32_t b2 = 0;
+                    if (lane == 0) b2 = atomicAdd(wl_count, (uint32_t)__popcll(em));
+                    b2 = __builtin_amdgcn_readfirstlane(b2);
+                    if (emit) worklist[b2 + __popcll(em & ((1ull << lane) - 1))] = o + rk;
+                }
             }
         }
-        if (lane == 0) {
-            strand_ncand[rs] = nc;
-            if (nc) {
-                worklist[atomicAdd(wl_count, 1u)] = rs;
-                atomicAdd(n_cand_total, (unsigned long long)nc);
-            }
-        }
+        if (lane == 0) strand_ncand[rs] = nc;
+        cand_sum += nc;
     }
+    if (pend) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(wl_count, pend);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < pend) worklist[base + lane] = pend_buf[lane];
+    }
+    if (lane == 0 && cand_sum) atomicAdd(n_cand_total, cand_sum);
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4: verification.  One wavefront per strand walks its ranked candidates in order; each
-// candidate's window is swept once by an anti-diagonal pipeline over the lanes (lane l owns read
-// rows [l*R, l*R+R)), computing in packed 16-bit halves of one register
+// K4: verification.  A wavefront is four 16-lane groups (one DPP row each); every group walks the
+// ranked candidates of one strand in the reference's order (index.rs:384-428).  A candidate's
+// window is swept once by an anti-diagonal pipeline over the group's lanes: lane g owns R
+// consecutive read rows, gets the row above from lane g-1 through a DPP row shift, and the window
+// symbols from an LDS ring staged once per candidate.  Each cell carries, in the two 16-bit halves
+// of one register,
 //   low  half: the Smith-Waterman local score   H = max(0, diag+s, up-1, left-1)   (ssw.c:123-328
 //              with the matrix of ssw/src/lib.rs:11-16 and gap 1/1; equals the striped byte
 //              kernel while the score stays below 254, i.e. for every read up to 253 bases)
 //   high half: the negated semi-global edit distance -D, so that
-//              -D = max(diag-delta, up-1, left-1) shares the same max/add instructions
+//              -D = max(diag-delta, up-1, left-1) shares the same packed max/add instructions
 //              (align.rs:28-85: first row 0, first column i, answer = min of the last row).
+// Reads shorter than 16*R rows are padded at the top with rows that behave like the zero
+// boundary of both recurrences, so the last read row is always row R-1 of lane 15.
 // ---------------------------------------------------------------------------------------------
 typedef short pk16 __attribute__((ext_vector_type(2)));
 
@@ -572,139 +641,174 @@ __device__ inline pk16 pk(int lo, int hi) {
     return r;
 }
 __device__ inline pk16 pk_max(pk16 a, pk16 b) { return __builtin_elementwise_max(a, b); }
-__device__ inline uint32_t pk_bits(pk16 a) { return __builtin_bit_cast(uint32_t, a); }
-__device__ inline pk16 pk_from_bits(uint32_t u) { return __builtin_bit_cast(pk16, u); }
+__device__ inline int pk_bits(pk16 a) { return __builtin_bit_cast(int, a); }
+__device__ inline pk16 pk_from_bits(int u) { return __builtin_bit_cast(pk16, u); }
 
-constexpr uint32_t kRingChunk = 256;             // window bytes staged per refill
-constexpr uint32_t kRingBytes = 2 * kRingChunk;  // two chunks: lanes lag the head by < 64 columns
+constexpr uint32_t kGroup = 16;
+constexpr uint32_t kRing = 1024;  // window bytes resident per group
 
+// value of lane g-1 of the same 16-lane row (row_shr:1); lane 0 of a row gets 0
+__device__ inline int row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true); }
+
+__device__ inline uint32_t group_ballot(bool p, uint32_t group) { return (uint32_t)(__ballot(p) >> (group * kGroup)) & 0xffffu; }
+
+enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2 };
+
+// One work item = one candidate (index into cand[]).  Items of a round are independent; a failed
+// candidate pushes the next candidate of the same TaxID (rank order) onto the next round's list.
 template <int R>
-__device__ void dp_sweep(const uint8_t* __restrict__ text, uint32_t text_n, uint32_t wstart, uint32_t Wn,
-                         const uint32_t (&qc)[R], uint32_t L, uint8_t* ring, uint32_t* sw_out, uint32_t* ed_out) {
+__global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
+    __shared__ uint8_t ring_all[256 / kGroup][kRing];
     const uint32_t lane = lane_id();
-    const uint32_t nl = (L + R - 1) / R;  // lanes that own at least one read row
-    const uint32_t row0 = lane * R;
-    pk16 h[R], mv[R];
+    const uint32_t gl = lane & (kGroup - 1);  // lane inside the group
+    uint8_t* ring = ring_all[threadIdx.x / kGroup];
+    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
+    const uint32_t n_groups = gridDim.x * blockDim.x / kGroup;
+    const uint32_t n_work = *a.wl_count;
+    const pk16 one = pk(1, 1), miss = pk(-1, -1);
+    const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
+                                               : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
+
+    uint32_t phase = PH_FETCH;
+    uint32_t w = gid;
+    uint32_t g = 0, o = 0, ED = 0, thr = 0;
+    bool thr_wrapped = false;
+    uint32_t qc[R];
+    pk16 clampRow[R];
+    uint32_t t = 0, steps = 0, Wn = 0, wstart = 0, c_next = 7;
+    uint32_t c_tax = 0, c_gi = 0, c_off = 0;
+    pk16 h[R], up_prev = pk(0, 0), best = pk(0, -32768), last = pk(0, -32768);
+    unsigned long long verified = 0, wbytes = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
-        h[r] = pk(0, -(int)(row0 + r + 1));            // column-0 boundary: H = 0, D[i][0] = i
-        mv[r] = qc[r] == kCodeN ? pk(1, -1) : pk(1, 0);  // N/N scores +1 in SW, never matches in edit distance
+        qc[r] = 6;
+        clampRow[r] = pk(0, 0);
+        h[r] = pk(0, 0);
     }
-    pk16 up_prev = pk(0, -(int)row0);
-    pk16 best = pk(0, -32768);
-    pk16 last = pk(0, -(int)L);  // min over the last row starts at D[L][0] = L
-    const int rstar = (int)((L - 1) % R);
-    const pk16 one = pk(1, 1), miss = pk(-1, -1), clamp = pk(0, -32768);
-    const uint32_t steps = Wn + nl - 1;
-    for (uint32_t t = 0; t < steps; t++) {
-        if ((t & (kRingChunk - 1)) == 0 && t < Wn) {
-            // stage window columns [t, t+256) into the ring half t/256 & 1
-            uint32_t half = (t / kRingChunk) & 1;
+
+    for (;;) {
+        if (phase == PH_FETCH) {
+            if (w < n_work) {
+                g = a.worklist[w];
+                w += n_groups;
+                const uint4 c = a.cand[g];
+                const uint32_t rs = a.cand_rs[g];
+                const DevBin bin = ix.bins[c.z];
+                const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
+                o = a.strand_off[rs];
+                const uint32_t b0 = a.read_off[r_];
+                const uint32_t L = a.read_off[r_ + 1] - b0;
+                ED = (uint32_t)ceil((double)L * a.edit_rate);  // index.rs:281-282
+                thr_wrapped = 2ull * ED > (uint64_t)L;         // usize wrap of index.rs:406: nothing can pass
+                thr = L - 2 * ED;
+                const uint8_t* read = a.bases + b0;
+                const int pad = (int)(kGroup * R) - (int)L;
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                uint32_t col = t + lane * 4 + k;
-                uint32_t pos = wstart + col;
-                uint8_t c = (col < Wn && pos < text_n) ? text[pos] : (uint8_t)7;
-                ring[half * kRingChunk + lane * 4 + k] = c;
+                for (int r = 0; r < R; r++) {
+                    int p = (int)(gl * R + r) - pad;  // read position of this row, < 0 for padding
+                    qc[r] = p >= 0 ? strand_code(read, L, strand, (uint32_t)p) : 6u;
+                    clampRow[r] = p >= 0 ? pk(0, -32768) : pk(0, 0);
+                    h[r] = pk(0, p >= 0 ? -(p + 1) : 0);  // column 0: H = 0, D[i][0] = i
+                }
+                {
+                    int p0 = (int)(gl * R) - pad;  // row above this lane's first row, at column 0
+                    up_prev = pk(0, p0 > 0 ? -p0 : 0);
+                }
+                wstart = c.x;
+                Wn = c.y - c.x;
+                c_tax = bin.tax_id;
+                c_gi = bin.gi;
+                c_off = c.x >= bin.start ? c.x - bin.start : 0;  // index.rs:416
+                verified++;
+                wbytes += Wn;
+                const uint32_t lim = min(Wn, kRing);
+                for (uint32_t base = 0; base < lim; base += 4 * kGroup) {
+                    uint8_t v[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t col = base + k * kGroup + gl, pos = wstart + col;
+                        v[k] = (col < lim && pos < ix.n) ? ix.text[pos] : (uint8_t)7;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t col = base + k * kGroup + gl;
+                        if (col < lim) ring[col] = v[k];
+                    }
+                }
+                best = pk(0, -32768);
+                last = h[R - 1];  // min over the last row starts at D[L][0] (only lane 15 is read)
+                t = 0;
+                steps = Wn + kGroup - 1;
+                c_next = ring[(0u - gl) & (kRing - 1)];
+                phase = PH_SWEEP;
+            } else {
+                phase = PH_DONE;
             }
         }
-        uint32_t in_bits = __shfl_up(pk_bits(h[R - 1]), 1);
-        pk16 in = lane == 0 ? pk(0, 0) : pk_from_bits(in_bits);  // top boundary: H = 0, D[0][j] = 0
-        int j = (int)t - (int)lane;
-        if (j >= 0 && j < (int)Wn && lane < nl) {
-            uint32_t c = ring[(uint32_t)j & (kRingBytes - 1)];
-            pk16 diag = up_prev, up = in;
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                pk16 sv = qc[r] == c ? mv[r] : miss;
-                pk16 x = diag + sv;
-                pk16 y = pk_max(up, h[r]) - one;
-                pk16 v = pk_max(pk_max(x, y), clamp);
-                diag = h[r];
-                h[r] = v;
-                up = v;
-                best = pk_max(best, v);
-                if (r == rstar) last = pk_max(last, v);
+        if (__all(phase == PH_DONE)) break;
+        if (phase == PH_SWEEP) {
+            // windows longer than the ring: once every lane has crossed a half boundary b (lane 15 lags
+            // by 15 columns), overwrite columns [b-512, b) with [b+512, b+1024)
+            if (Wn > kRing && t >= kRing / 2 + kGroup && ((t - kGroup) & (kRing / 2 - 1)) == 0) {
+                const uint32_t from = (t - kGroup) + kRing / 2, to = min(Wn, from + kRing / 2);
+                for (uint32_t col = from + gl; col < to; col += kGroup) {
+                    uint32_t pos = wstart + col;
+                    ring[col & (kRing - 1)] = pos < ix.n ? ix.text[pos] : (uint8_t)7;
+                }
             }
-            up_prev = in;
-        }
-    }
-    int sw = best.x;
-    for (int d = 32; d > 0; d >>= 1) sw = max(sw, __shfl_xor(sw, d));
-    int lastv = __shfl((int)last.y, (int)((L - 1) / R));
-    *sw_out = (uint32_t)sw;
-    *ed_out = (uint32_t)(-lastv);
-}
-
-template <int R>
-__device__ void verify_strand(const DevIndexView& ix, const VerifyArgs& a, uint32_t rs, uint8_t* ring,
-                              unsigned long long* wave_verified, unsigned long long* wave_wbytes) {
-    const uint32_t lane = lane_id();
-    const uint32_t r = a.r0 + (rs >> 1), strand = rs & 1;
-    const uint32_t o = a.strand_off[rs];
-    const uint32_t nc = __builtin_amdgcn_readfirstlane(a.strand_ncand[rs]);
-    const uint32_t b0 = a.read_off[r], L = a.read_off[r + 1] - b0;
-    const uint32_t ED = (uint32_t)ceil((double)L * a.edit_rate);
-    const uint64_t thr = (uint64_t)L - 2ull * ED;  // usize arithmetic, wraps like the release build (index.rs:406)
-    const uint8_t* read = a.bases + b0;
-    uint32_t qc[R];
+            const uint32_t c = c_next;
+            const int j = (int)t - (int)gl;
+            c_next = ring[(uint32_t)(j + 1) & (kRing - 1)];
+            int in_bits = row_shr1(pk_bits(h[R - 1]));
+            const pk16 in = pk_from_bits(in_bits);  // lane 0 of the row reads 0: H = 0, D[0][j] = 0
+            if (j >= 0 && j < (int)Wn) {
+                const pk16 mvc = c == kCodeN ? pk(1, -1) : pk(1, 0);  // N/N: +1 in SW, never a match in edit distance
+                pk16 diag = up_prev, up = in;
 #pragma unroll
-    for (int k = 0; k < R; k++) {
-        uint32_t row = lane * R + k;
-        qc[k] = row < L ? strand_code(read, L, strand, row) : 6u;
+                for (int r = 0; r < R; r++) {
+                    pk16 sv = qc[r] == c ? mvc : miss;
+                    pk16 x = diag + sv;
+                    pk16 y = pk_max(up, h[r]) - one;
+                    pk16 v = pk_max(pk_max(x, y), clampRow[r]);
+                    diag = h[r];
+                    h[r] = v;
+                    up = v;
+                    best = pk_max(best, v);
+                }
+                last = pk_max(last, h[R - 1]);
+                up_prev = in;
+            }
+            t++;
+            if (t >= steps) {
+                int sw = best.x;
+                sw = max(sw, __shfl_xor(sw, 1));
+                sw = max(sw, __shfl_xor(sw, 2));
+                sw = max(sw, __shfl_xor(sw, 4));
+                sw = max(sw, __shfl_xor(sw, 8));
+                const int lastv = __shfl((int)last.y, (int)(lane | (kGroup - 1)));
+                const uint32_t ed = (uint32_t)(-lastv);
+                const bool pass = !thr_wrapped && (uint32_t)sw >= thr && ed <= ED;  // index.rs:406,410
+                if (gl == 0) {
+                    if (pass) {
+                        a.out[g] = make_uint4(c_tax, c_gi, c_off, ed);
+                        a.cand_status[g] = 2;
+                    } else {
+                        a.cand_status[g] = 1;
+                        const uint32_t nxt = a.cand_next[g];  // next candidate of this TaxId in rank order
+                        if (nxt != 0xffffffffu && nxt < maxc) a.worklist_next[atomicAdd(a.wl_next_count, 1u)] = o + nxt;
+                    }
+                }
+                phase = PH_FETCH;
+            }
+        }
     }
-    uint32_t my_tax = 0;  // lane m remembers the m-th matched TaxId (m < 64)
-    uint32_t nout = 0, checked = 0;
-    uint4* out = a.out + o;
-    for (uint32_t i = 0; i < nc; i++) {
-        if (a.max_candidates >= 0 && (uint64_t)checked >= (uint64_t)a.max_candidates) break;  // index.rs:385-389
-        checked++;
-        uint4 c = a.cand[o + i];
-        DevBin bin = ix.bins[c.z];
-        // matches.iter().find(...), index.rs:393
-        bool dup = __any(lane < min(nout, (uint32_t)kWave) && my_tax == bin.tax_id);
-        for (uint32_t m = kWave + lane; !dup && m - lane < nout; m += kWave) {
-            uint32_t t = m < nout ? (uint32_t)__hip_atomic_load(&out[m].x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
-                                  : bin.tax_id + 1;
-            dup = __any(m < nout && t == bin.tax_id);
-        }
-        if (dup) continue;
-        uint32_t Wn = c.y - c.x;
-        uint32_t sw = 0, ed = 0;
-        dp_sweep<R>(ix.text, ix.n, c.x, Wn, qc, L, ring, &sw, &ed);
-        (*wave_verified)++;
-        (*wave_wbytes) += Wn;
-        if ((uint64_t)sw >= thr && ed <= ED) {  // index.rs:406,410
-            if (lane == (nout & (kWave - 1)) && nout < kWave) my_tax = bin.tax_id;
-            if (lane == 0) out[nout] = make_uint4(bin.tax_id, bin.gi, c.x >= bin.start ? c.x - bin.start : 0, ed);
-            wave_mem_sync();
-            nout++;
-            if (a.max_assignments >= 0 && (uint64_t)nout >= (uint64_t)a.max_assignments) break;  // index.rs:421-425
-        }
+    if (gl != 0) {
+        verified = 0;
+        wbytes = 0;
     }
-    if (lane == 0) a.strand_nout[rs] = nout;
-}
-
-__global__ __launch_bounds__(256) void k_verify(DevIndexView ix, VerifyArgs a) {
-    __shared__ uint8_t ring_all[4][kRingBytes];
-    uint8_t* ring = ring_all[threadIdx.x / kWave];
-    const uint32_t lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
-    const uint32_t n_work = *a.wl_count;
-    unsigned long long verified = 0, wbytes = 0;
-    for (uint32_t w = wave; w < n_work; w += n_waves) {
-        uint32_t rs = a.worklist[w];
-        uint32_t r = a.r0 + (rs >> 1);
-        uint32_t L = a.read_off[r + 1] - a.read_off[r];
-        uint32_t R = (L + kWave - 1) / kWave;
-        switch (R) {
-        case 1: verify_strand<1>(ix, a, rs, ring, &verified, &wbytes); break;
-        case 2: verify_strand<2>(ix, a, rs, ring, &verified, &wbytes); break;
-        case 3: verify_strand<3>(ix, a, rs, ring, &verified, &wbytes); break;
-        case 4: verify_strand<4>(ix, a, rs, ring, &verified, &wbytes); break;
-        default: break;  // host rejects longer reads (MTSV_E_LIMIT)
-        }
+    for (int d = 32; d > 0; d >>= 1) {
+        verified += __shfl_down(verified, d);
+        wbytes += __shfl_down(wbytes, d);
     }
     if (lane == 0 && verified) {
         atomicAdd(a.n_verified, verified);
@@ -712,10 +816,30 @@ __global__ __launch_bounds__(256) void k_verify(DevIndexView ix, VerifyArgs a) {
     }
 }
 
-// strands without candidates never reach k_verify: zero their output count
-__global__ __launch_bounds__(256) void k_zero_u32(uint32_t* p, uint32_t n) {
-    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0;
+// The ordered selection loop of index.rs:384-428 over the verified statuses: a candidate is in
+// status "pass" only if every earlier candidate of its TaxId failed, so the duplicate-TaxId skip
+// has already been applied; what remains are the two cut-offs and the rank order of the hits.
+__global__ __launch_bounds__(256) void k_resolve(uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,
+                                                 const uint32_t* __restrict__ strand_off,
+                                                 const uint32_t* __restrict__ strand_ncand,
+                                                 const uint32_t* __restrict__ cand_status, uint4* __restrict__ out,
+                                                 uint32_t* __restrict__ strand_nout) {
+    uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
+    if (rs >= n_strands) return;
+    uint32_t nc = strand_ncand[rs];
+    uint32_t nout = 0;
+    if (nc) {
+        uint32_t o = strand_off[rs];
+        if (max_candidates >= 0 && (uint64_t)nc > (uint64_t)max_candidates) nc = (uint32_t)max_candidates;  // index.rs:385-389
+        for (uint32_t i = 0; i < nc; i++) {
+            if (cand_status[o + i] == 2) {
+                if (nout != i) out[o + nout] = out[o + i];
+                nout++;
+                if (max_assignments >= 0 && (uint64_t)nout >= (uint64_t)max_assignments) break;  // index.rs:421-425
+            }
+        }
+    }
+    strand_nout[rs] = nout;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -790,19 +914,37 @@ void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_ho
 }
 
 void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,
-                     double edit_rate, double min_seed, const uint32_t* strand_off, const uint32_t* strand_nseeds,
-                     const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key, uint64_t* cand_tmp, uint4* cand,
+                     double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
+                     const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
+                     uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_rs, uint32_t* cand_status,
                      uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, unsigned long long* n_cand_total) {
     uint32_t blocks = std::min<uint32_t>(cdiv(n_strands, 4), 256 * 8);
     hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, read_off, r0, n_strands, edit_rate, min_seed,
-                       strand_off, strand_nseeds, hit_ref, hit_q, hit_key, cand_tmp, cand, strand_ncand, worklist, wl_count,
-                       n_cand_total);
+                       max_candidates, strand_off, strand_nseeds, hit_ref, hit_q, hit_key, cand_tmp, cand, cand_next, cand_rs,
+                       cand_status, strand_ncand, worklist, wl_count, n_cand_total);
 }
 
-void launch_verify(hipStream_t s, const DevIndexView& ix, const VerifyArgs& a, uint32_t n_strands) {
-    hipLaunchKernelGGL(k_zero_u32, dim3(cdiv(n_strands, 256)), dim3(256), 0, s, a.strand_nout, n_strands);
-    uint32_t blocks = std::min<uint32_t>(cdiv(n_strands, 4), 256 * 8);
-    hipLaunchKernelGGL(k_verify, dim3(blocks), dim3(256), 0, s, ix, a);
+void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
+    // 16 candidates per 256-thread block in flight; persistent groups stride over the worklist
+    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 16), 256 * 8));
+    uint32_t R = (max_len + kGroup - 1) / kGroup;
+#define EVAL_CASE(RR) hipLaunchKernelGGL(k_evaluate<RR>, dim3(blocks), dim3(256), 0, s, ix, a)
+    if (R <= 2) EVAL_CASE(2);
+    else if (R <= 4) EVAL_CASE(4);
+    else if (R <= 5) EVAL_CASE(5);
+    else if (R <= 7) EVAL_CASE(7);
+    else if (R <= 8) EVAL_CASE(8);
+    else if (R <= 10) EVAL_CASE(10);
+    else if (R <= 13) EVAL_CASE(13);
+    else EVAL_CASE(16);
+#undef EVAL_CASE
+}
+
+void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,
+                    const uint32_t* strand_off, const uint32_t* strand_ncand, const uint32_t* cand_status, uint4* out,
+                    uint32_t* strand_nout) {
+    hipLaunchKernelGGL(k_resolve, dim3(cdiv(n_strands, 256)), dim3(256), 0, s, n_strands, max_candidates, max_assignments,
+                       strand_off, strand_ncand, cand_status, out, strand_nout);
 }
 
 void launch_gather(hipStream_t s, uint32_t n_strands, uint32_t r0, const uint32_t* strand_off, const uint32_t* strand_nout,

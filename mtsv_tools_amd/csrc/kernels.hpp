@@ -17,25 +17,27 @@ struct DevHit {  // byte-identical to mtsv_hit (include/mtsv_amd.h)
 };
 static_assert(sizeof(DevHit) == 32, "DevHit must match mtsv_hit");
 
-struct VerifyArgs {
+struct EvalArgs {
     const uint8_t* bases;
     const uint32_t* read_off;
     uint32_t r0;
     double edit_rate;
     int64_t max_candidates;
-    int64_t max_assignments;
     const uint32_t* strand_off;
-    const uint32_t* strand_ncand;
-    const uint4* cand;
-    const uint32_t* worklist;
+    const uint4* cand;            // (start, end, bin, num_seeds) in rank order per strand
+    const uint32_t* cand_next;    // rank of the next candidate with the same TaxId, 0xffffffff = none
+    const uint32_t* cand_rs;      // strand of the candidate
+    uint32_t* cand_status;        // 0 not verified, 1 failed, 2 passed
+    const uint32_t* worklist;     // candidate indices of this round
     const uint32_t* wl_count;
-    uint4* out;            // per-strand hit segments: (tax_id, gi, offset, edit)
-    uint32_t* strand_nout;
+    uint32_t* worklist_next;      // filled by failures for the next round
+    uint32_t* wl_next_count;
+    uint4* out;                   // out[candidate] = (tax_id, gi, offset, edit) when it passed
     unsigned long long* n_verified;
     unsigned long long* window_bytes;
 };
 
-constexpr uint32_t kMaxReadLen = 256;  // 4 read rows per lane in k_verify
+constexpr uint32_t kMaxReadLen = 253;  // 16 lanes x 16 rows in k_verify; 254+ needs the SSW word-kernel path
 
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt);
@@ -51,10 +53,14 @@ void launch_expand(hipStream_t s, const DevIndexView& ix, uint32_t n_strands, ui
 void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_host, const uint32_t* total_hits_dev,
                    const uint32_t* hit_row, uint32_t* hit_ref, unsigned long long* lf_steps);
 void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,
-                     double edit_rate, double min_seed, const uint32_t* strand_off, const uint32_t* strand_nseeds,
-                     const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key, uint64_t* cand_tmp, uint4* cand,
+                     double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
+                     const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
+                     uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_rs, uint32_t* cand_status,
                      uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, unsigned long long* n_cand_total);
-void launch_verify(hipStream_t s, const DevIndexView& ix, const VerifyArgs& a, uint32_t n_strands);
+void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
+void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,
+                    const uint32_t* strand_off, const uint32_t* strand_ncand, const uint32_t* cand_status, uint4* out,
+                    uint32_t* strand_nout);
 void launch_gather(hipStream_t s, uint32_t n_strands, uint32_t r0, const uint32_t* strand_off, const uint32_t* strand_nout,
                    const uint32_t* out_off, const uint4* out, DevHit* hits, uint64_t hits_base);
 
