@@ -656,7 +656,13 @@ enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2 };
 
 // One work item = one candidate (index into cand[]).  Items of a round are independent; a failed
 // candidate pushes the next candidate of the same TaxID (rank order) onto the next round's list.
-template <int R>
+// WORD: reads of 254+ bases can push the byte kernel of ssw.c to its overflow value 255 (score >= 254,
+// ssw.c:271,302), after which ssw_align reruns sw_sse2_word (ssw.c:789-792).  With gap open == gap
+// extend that kernel's lazy-F loop (ssw.c:452-463) always leaves after its first cell, so a vertical
+// gap crosses a stripe boundary (read rows that are multiples of segLen = ceil(L/8)) by one cell only
+// and E never sees the lazy correction.  Row-wise that is: hb = max(0, diag+s, left_pre-1);
+// h = max(hb, up_pre-1); pre = boundary row ? hb : h -- computed here next to the exact score.
+template <int R, bool WORD>
 __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
     __shared__ uint8_t ring_all[256 / kGroup][kRing];
     const uint32_t lane = lane_id();
@@ -678,6 +684,10 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
     uint32_t t = 0, steps = 0, Wn = 0, wstart = 0, c_next = 7;
     uint32_t c_tax = 0, c_gi = 0, c_off = 0;
     pk16 h[R], up_prev = pk(0, 0), best = pk(0, -32768), last = pk(0, -32768);
+    // word-kernel emulation: post-lazy H, pre-lazy H, boundary-row mask, running max
+    int hw[WORD ? R : 1], hwp[WORD ? R : 1];
+    int upw_prev = 0, bestw = 0;
+    uint32_t bmask = 0;
     unsigned long long verified = 0, wbytes = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -713,6 +723,19 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                 {
                     int p0 = (int)(gl * R) - pad;  // row above this lane's first row, at column 0
                     up_prev = pk(0, p0 > 0 ? -p0 : 0);
+                }
+                if (WORD) {
+                    const int seg8 = (int)((L + 7) / 8);  // qP_word, ssw.c:336
+                    bmask = 0;
+                    upw_prev = 0;
+                    bestw = 0;
+#pragma unroll
+                    for (int r = 0; r < (WORD ? R : 1); r++) {
+                        int p = (int)(gl * R + r) - pad;
+                        if (p >= 0 && p % seg8 == 0) bmask |= 1u << r;
+                        hw[r] = 0;
+                        hwp[r] = 0;
+                    }
                 }
                 wstart = c.x;
                 Wn = c.y - c.x;
@@ -761,6 +784,8 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
             c_next = ring[(uint32_t)(j + 1) & (kRing - 1)];
             int in_bits = row_shr1(pk_bits(h[R - 1]));
             const pk16 in = pk_from_bits(in_bits);  // lane 0 of the row reads 0: H = 0, D[0][j] = 0
+            int inw = 0;
+            if (WORD) inw = row_shr1((hw[(WORD ? R : 1) - 1] << 16) | hwp[(WORD ? R : 1) - 1]);  // (post, pre) of the row above
             if (j >= 0 && j < (int)Wn) {
                 const pk16 mvc = c == kCodeN ? pk(1, -1) : pk(1, 0);  // N/N: +1 in SW, never a match in edit distance
                 pk16 diag = up_prev, up = in;
@@ -777,6 +802,22 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                 }
                 last = pk_max(last, h[R - 1]);
                 up_prev = in;
+                if (WORD) {
+                    int diagw = upw_prev, uppre = inw & 0xffff;
+#pragma unroll
+                    for (int r = 0; r < (WORD ? R : 1); r++) {
+                        int sc = qc[r] == c ? 1 : -1;
+                        int hb = max(max(diagw + sc, hwp[r] - 1), 0);
+                        int hh = max(hb, uppre - 1);
+                        int pre = ((bmask >> r) & 1u) ? hb : hh;
+                        diagw = hw[r];
+                        hw[r] = hh;
+                        hwp[r] = pre;
+                        uppre = pre;
+                        bestw = max(bestw, hh);
+                    }
+                    upw_prev = inw >> 16;
+                }
             }
             t++;
             if (t >= steps) {
@@ -787,6 +828,14 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                 sw = max(sw, __shfl_xor(sw, 8));
                 const int lastv = __shfl((int)last.y, (int)(lane | (kGroup - 1)));
                 const uint32_t ed = (uint32_t)(-lastv);
+                if (WORD) {
+                    int w2 = bestw;
+                    w2 = max(w2, __shfl_xor(w2, 1));
+                    w2 = max(w2, __shfl_xor(w2, 2));
+                    w2 = max(w2, __shfl_xor(w2, 4));
+                    w2 = max(w2, __shfl_xor(w2, 8));
+                    if (sw >= 254) sw = w2;  // byte kernel overflowed -> sw_sse2_word's score (ssw.c:789-792)
+                }
                 const bool pass = !thr_wrapped && (uint32_t)sw >= thr && ed <= ED;  // index.rs:406,410
                 if (gl == 0) {
                     if (pass) {
@@ -928,15 +977,22 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
     // 16 candidates per 256-thread block in flight; persistent groups stride over the worklist
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 16), 256 * 8));
     uint32_t R = (max_len + kGroup - 1) / kGroup;
-#define EVAL_CASE(RR) hipLaunchKernelGGL(k_evaluate<RR>, dim3(blocks), dim3(256), 0, s, ix, a)
-    if (R <= 2) EVAL_CASE(2);
-    else if (R <= 4) EVAL_CASE(4);
-    else if (R <= 5) EVAL_CASE(5);
-    else if (R <= 7) EVAL_CASE(7);
-    else if (R <= 8) EVAL_CASE(8);
-    else if (R <= 10) EVAL_CASE(10);
-    else if (R <= 13) EVAL_CASE(13);
-    else EVAL_CASE(16);
+#define EVAL_CASE(RR, WW) hipLaunchKernelGGL((k_evaluate<RR, WW>), dim3(blocks), dim3(256), 0, s, ix, a)
+    if (max_len < 254) {
+        if (R <= 2) EVAL_CASE(2, false);
+        else if (R <= 4) EVAL_CASE(4, false);
+        else if (R <= 5) EVAL_CASE(5, false);
+        else if (R <= 7) EVAL_CASE(7, false);
+        else if (R <= 8) EVAL_CASE(8, false);
+        else if (R <= 10) EVAL_CASE(10, false);
+        else if (R <= 13) EVAL_CASE(13, false);
+        else EVAL_CASE(16, false);
+    } else {
+        if (R <= 16) EVAL_CASE(16, true);
+        else if (R <= 20) EVAL_CASE(20, true);
+        else if (R <= 24) EVAL_CASE(24, true);
+        else EVAL_CASE(32, true);
+    }
 #undef EVAL_CASE
 }
 

@@ -37,7 +37,7 @@ struct EvalArgs {
     unsigned long long* window_bytes;
 };
 
-constexpr uint32_t kMaxReadLen = 253;  // 16 lanes x 16 rows in k_verify; 254+ needs the SSW word-kernel path
+constexpr uint32_t kMaxReadLen = 512;  // 16 lanes x 32 read rows per lane in k_evaluate
 
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt);

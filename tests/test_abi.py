@@ -1,0 +1,104 @@
+"""CPU tests of the product's C ABI: the library loads, exports every symbol include/mtsv_amd.h
+declares, mirrors the reference's defaults and output grammar, and refuses to run without a GPU."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import helpers
+import mtsv_tools_amd as M
+from mtsv_tools_amd import _lib
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_functions():
+    src = open(os.path.join(ROOT, "include", "mtsv_amd.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(mtsv_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(M.lib_path())
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mtsv_amd.h but not exported"
+    assert set(names) == set(_lib.EXPORTS)
+
+
+def test_struct_layouts_match_header():
+    assert M.HIT_DTYPE.itemsize == 32
+    assert ctypes.sizeof(M.Params) == 56
+
+
+def test_default_params_are_the_cli_defaults():
+    # src/bin/mtsv-binner.rs:63-94
+    p = M.default_params()
+    assert (p.edit_rate, p.seed_size, p.seed_interval, p.min_seed) == (0.13, 18, 15, 0.015)
+    assert (p.max_hits, p.tune_max_hits, p.max_assignments, p.max_candidates) == (2000, 200, -1, -1)
+
+
+def test_no_cpu_fallback(tmp_path):
+    if M.device_count() > 0:
+        pytest.skip("a GPU is present")
+    ix = M.MGIndex.build([(1, 10, b"ACGTACGTAACCGGTTACGATCGATCGATCGTAGC" * 4)], threads=1)
+    bases, off = helpers.reads_to_batch([b"ACGTACGTAACCGGTTACGATCGATC"])
+    with pytest.raises(M.MtsvError) as e:
+        ix.bin_batch(bases, off, device=0)
+    assert e.value.code == _lib.E_DEVICE
+    with pytest.raises(M.MtsvError) as e:
+        ix.bin_batch(bases, off, device=-1)  # the survey's "-1 = CPU oracle" is deliberately not offered
+    assert e.value.code == _lib.E_ARG
+
+
+def test_format_results_equals_reference_vectors_and_oracle():
+    hits = np.zeros(3, dtype=M.HIT_DTYPE)
+    hits["read"] = 1
+    hits["tax_id"] = [2, 2, 5]
+    hits["gi"] = [10, 11, 12]
+    hits["offset"] = [3, 8, 1]
+    hits["edit"] = [7, 4, 9]
+    assert M.format_results(hits, ["R0", "R1_1_0_0"]) == "R1_1_0_0:2=4,5=9\n"  # binner.rs:440-455
+    hits = np.zeros(4, dtype=M.HIT_DTYPE)
+    hits["tax_id"] = [2, 2, 2, 5]
+    hits["gi"] = [10, 10, 11, 12]
+    hits["offset"] = [3, 3, 8, 1]
+    hits["edit"] = [7, 4, 6, 9]
+    assert M.format_results(hits, ["R1_1_0_0"], True) == "R1_1_0_0:2-10-3=4,2-11-8=6,5-12-1=9\n"  # :457-472
+    assert M.format_results(np.zeros(0, dtype=M.HIT_DTYPE), ["a", "b"]) == ""
+    # random hit sets: product formatter == oracle formatter
+    rng = np.random.default_rng(1)
+    for long_fmt in (False, True):
+        n = 200
+        h = np.zeros(n, dtype=M.HIT_DTYPE)
+        h["read"] = np.sort(rng.integers(0, 30, n))
+        h["tax_id"] = rng.integers(0, 6, n)
+        h["gi"] = rng.integers(0, 3, n)
+        h["offset"] = rng.integers(0, 4, n)
+        h["edit"] = rng.integers(0, 20, n)
+        ids = [f"read{i} x" for i in range(30)]
+        oh = np.zeros(n, dtype=O.HIT_DTYPE)
+        for f in ("read", "tax_id", "gi", "offset", "edit"):
+            oh[f] = h[f]
+        want = "".join(O.format_line(ids[r], oh[oh["read"] == r], long_fmt) for r in range(30))
+        assert M.format_results(h, ids, long_fmt) == want
+
+
+def test_format_results_rejects_unordered_hits():
+    h = np.zeros(2, dtype=M.HIT_DTYPE)
+    h["read"] = [1, 0]
+    with pytest.raises(M.MtsvError):
+        M.format_results(h, ["a", "b"])
+
+
+def test_synthetic_workload_is_deterministic():
+    a = M.MGIndex.synth(5, 4, 2, 3000, threads=2)
+    b = M.MGIndex.synth(5, 4, 2, 3000, threads=5)
+    ra, oa = M.synth_reads(a, 9, 500, 100)
+    rb, ob = M.synth_reads(b, 9, 500, 100)
+    assert np.array_equal(ra, rb) and np.array_equal(oa, ob)
+    assert a.info()["n"] == 4 * 2 * 3000 + 1

@@ -1,21 +1,42 @@
 """-m gpu parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on
-the same seeded inputs.  Bit-exact: every field of every hit, in order."""
+the same seeded inputs.  Bit-exact: every field of every hit, in the reference's order."""
+import os
+
 import numpy as np
 import pytest
 
+import helpers
 import mtsv_tools_amd as M
+from helpers import assert_same_hits
+from mtsv_tools_amd import _lib
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
 
-FIELDS = ("read", "tax_id", "gi", "edit", "strand", "offset")
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+ALL_FLAGS = [M.DEV_SAMPLED_SA_ONLY | M.DEV_NO_KMER_TABLE, M.DEV_SAMPLED_SA_ONLY, M.DEV_NO_KMER_TABLE, M.DEV_DEFAULT]
+
+PARAM_SETS = {
+    "default": {},
+    # SURVEY 8(c) stress set: every cut-off active
+    "stress": dict(max_hits=5, tune_max_hits=2, max_candidates=3, max_assignments=1, min_seed=0.5),
+    # short dense seeds: hundreds to thousands of hits per strand (sort / walk in L2 scratch), thinning
+    "dense": dict(seed_size=10, seed_interval=3, max_hits=100000, tune_max_hits=30),
+    "dense_nothin": dict(seed_size=11, seed_interval=4, max_hits=100000, tune_max_hits=100000, min_seed=0.1),
+    "exact_only": dict(edit_rate=0.0),
+    "loose": dict(edit_rate=0.3, max_candidates=40),
+    "wrapped_threshold": dict(edit_rate=0.6),      # 2*ED > L: usize wrap of index.rs:406, nothing passes
+    "all_seeds_needed": dict(min_seed=1.0),
+    "one_assignment": dict(max_assignments=1),
+    "two_candidates": dict(max_candidates=2),
+    "big_seed": dict(seed_size=31, seed_interval=7),
+}
 
 
-def assert_same_hits(got, want):
-    assert len(got) == len(want), (len(got), len(want))
-    for f in FIELDS:
-        bad = np.nonzero(got[f] != want[f])[0]
-        assert len(bad) == 0, (f, bad[:5], got[bad[:5]], want[bad[:5]])
+def both_params(**over):
+    mp = M.default_params(**{("seed_interval" if k == "seed_gap" else k): v for k, v in over.items()})
+    op = O.default_params(**{("seed_gap" if k == "seed_interval" else k): v for k, v in over.items()})
+    return mp, op
 
 
 @pytest.fixture(scope="module")
@@ -26,8 +47,17 @@ def small_db(tmp_path_factory):
     return ix, O.Index.read(p)
 
 
-@pytest.mark.parametrize("flags", [M.DEV_SAMPLED_SA_ONLY | M.DEV_NO_KMER_TABLE, M.DEV_SAMPLED_SA_ONLY,
-                                   M.DEV_NO_KMER_TABLE, M.DEV_DEFAULT])
+@pytest.fixture(scope="module")
+def tricky(tmp_path_factory):
+    entries, gene, unit = helpers.tricky_db(seed=7)
+    ix = M.MGIndex.build(entries, threads=4)
+    p = str(tmp_path_factory.mktemp("idx") / "tricky.idx")
+    ix.write(p)
+    reads = helpers.tricky_reads(entries, gene, unit, seed=11, n_each=50, lengths=(100, 150, 64, 253))
+    return ix, O.Index.read(p), reads
+
+
+@pytest.mark.parametrize("flags", ALL_FLAGS)
 @pytest.mark.parametrize("read_len", [100, 150])
 def test_default_params_match_oracle(small_db, flags, read_len):
     ix, orc = small_db
@@ -37,3 +67,175 @@ def test_default_params_match_oracle(small_db, flags, read_len):
     want, _ = orc.bin_batch(bases, off, O.default_params(), threads=8)
     assert len(want) > 1000
     assert_same_hits(got, want)
+
+
+@pytest.mark.parametrize("flags", [ALL_FLAGS[0], ALL_FLAGS[3]])
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_adversarial_database_all_parameter_sets(tricky, pname, flags):
+    """conserved genes (duplicate TaxIds, ties in the stable rank sort), tandem repeats (merged
+    windows longer than the LDS ring, thousands of seed hits), N runs, bin junctions, reads of mixed
+    length incl. shorter than a seed and empty, lower case and junk bytes"""
+    ix, orc, reads = tricky
+    mp, op = both_params(**PARAM_SETS[pname])
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0, flags)
+    got = ix.bin_batch(bases, off, mp, device=0)
+    want, ctr = orc.bin_batch(bases, off, op, threads=8)
+    if pname == "wrapped_threshold":
+        assert len(want) == 0
+    elif pname != "exact_only":
+        assert len(want) > 50
+    assert_same_hits(got, want)
+
+
+def test_committed_golden_result_lines(tricky):
+    """the committed end-to-end vectors (tests/golden/e2e_*.results) through the HIP path + the
+    product's formatter"""
+    entries = []
+    for line in open(os.path.join(GOLD, "e2e_db.fasta")):
+        if line.startswith(">"):
+            gi, tax = line[1:].split()[0].split("-")
+        else:
+            entries.append((int(tax), int(gi), line.strip().encode()))
+    reads = [l.rstrip("\n").encode("latin-1") for l in open(os.path.join(GOLD, "e2e_reads.txt"), encoding="latin-1")]
+    ix = M.MGIndex.build(entries, threads=4)
+    ix.to_device(0)
+    bases, off = helpers.reads_to_batch(reads)
+    ids = [f"r{i}" for i in range(len(reads))]
+    stress = dict(max_hits=5, tune_max_hits=2, max_candidates=3, max_assignments=1, min_seed=0.5)
+    for name, over in (("default", {}), ("stress", stress)):
+        hits = ix.bin_batch(bases, off, M.default_params(**over), device=0)
+        for long_fmt in (False, True):
+            want = open(os.path.join(GOLD, f"e2e_{name}{'_long' if long_fmt else ''}.results")).read()
+            assert M.format_results(hits, ids, long_fmt) == want
+
+
+def test_batch_split_when_hit_workspace_is_small(tricky):
+    ix, orc, reads = tricky
+    mp, op = both_params(**PARAM_SETS["dense_nothin"])
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want, _ = orc.bin_batch(bases, off, op, threads=8)
+    b = M.Batch(ix, 0, len(reads), len(bases), max_hits_ws=40000)
+    b.upload(bases, off)
+    b.run(mp)
+    st = b.stats()
+    assert st["n_passes"] > 1
+    assert_same_hits(b.download(), want)
+    # a workspace that cannot hold a single read's seed hits fails loudly
+    b2 = M.Batch(ix, 0, len(reads), len(bases), max_hits_ws=64)
+    b2.upload(bases, off)
+    with pytest.raises(M.MtsvError) as e:
+        b2.run(mp)
+    assert e.value.code == _lib.E_DEVICE
+
+
+def test_limits_and_argument_errors(small_db):
+    ix, _ = small_db
+    ix.to_device(0)
+    bases, off = helpers.reads_to_batch([b"ACGT" * 150])  # 600 bases > 512
+    with pytest.raises(M.MtsvError) as e:
+        ix.bin_batch(bases, off, device=0)
+    assert e.value.code == _lib.E_LIMIT
+    ok, off2 = helpers.reads_to_batch([b"ACGT" * 30])
+    for bad in (dict(edit_rate=1.5), dict(edit_rate=-0.1), dict(seed_size=0), dict(seed_interval=0)):
+        with pytest.raises(M.MtsvError) as e:
+            ix.bin_batch(ok, off2, M.default_params(**bad), device=0)
+        assert e.value.code == _lib.E_ARG
+    assert len(ix.bin_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64), device=0)) == 0  # empty batch
+
+
+@pytest.mark.parametrize("read_len", [254, 300, 400, 512])
+def test_long_reads_take_the_ssw_word_kernel_path(tricky, read_len):
+    """reads of 254+ bases whose score reaches 254 make ssw_align rerun sw_sse2_word (ssw.c:789-792),
+    whose lazy-F loop truncates vertical gaps at stripe boundaries: insertions planted there"""
+    import random
+    ix, orc, _ = tricky
+    entries, gene, unit = helpers.tricky_db(seed=7)
+    rng = random.Random(read_len)
+    texts = [e[2].upper() for e in entries if len(e[2]) > read_len + 200]
+    reads = []
+    seg = (read_len + 7) // 8
+    for i in range(150):
+        t = rng.choice(texts)
+        st = rng.randrange(0, len(t) - read_len - 40)
+        r = bytearray(t[st:st + read_len + 30])
+        for _ in range(rng.randrange(0, 4)):
+            b = rng.randrange(1, 8) * seg + rng.randrange(-2, 3)
+            k = rng.randrange(1, 7)
+            if rng.random() < 0.6:
+                r[b:b] = helpers.rnd_seq(rng, k)
+            else:
+                del r[b:b + k]
+        for _ in range(rng.randrange(0, 8)):
+            r[rng.randrange(read_len)] = rng.choice(b"ACGTN")
+        r = bytes(r[:read_len])
+        reads.append(r if i % 2 else helpers.revcomp(r))
+    bases, off = helpers.reads_to_batch(reads)
+    for over in ({}, dict(edit_rate=0.05), dict(edit_rate=0.02)):
+        mp, op = both_params(**over)
+        ix.to_device(0)
+        got = ix.bin_batch(bases, off, mp, device=0)
+        want, _ = orc.bin_batch(bases, off, op, threads=8)
+        assert len(want) > 20
+        assert_same_hits(got, want)
+
+
+def test_counters_equal_oracle_counters(small_db):
+    """the device counts the same work the reference does (SURVEY 8(d) accounting)"""
+    ix, orc = small_db
+    bases, off = M.synth_reads(ix, seed=77, n_reads=5000, read_len=150)
+    ix.to_device(0, M.DEV_SAMPLED_SA_ONLY | M.DEV_NO_KMER_TABLE)
+    b = M.Batch(ix, 0, 5000, len(bases))
+    b.upload(bases, off)
+    b.run(M.default_params())
+    st = b.stats()
+    _, ctr = orc.bin_batch(bases, off, O.default_params(), threads=8)
+    assert st["n_seed_hits"] == ctr["H"]
+    assert st["lf_steps"] == ctr["S"]
+    assert st["n_candidates"] == ctr["n_cand"]
+    assert st["n_verified"] == ctr["n_sw"]
+    assert st["window_bytes"] == ctr["W"]
+    assert st["n_hits"] == ctr["R"]
+
+
+@pytest.fixture(scope="module")
+def medium():
+    ix = M.MGIndex.synth(seed=0x6D747376, n_taxa=64, gis_per_taxon=4, seq_len=40000)  # n ~ 1e7
+    ix.to_device(0)
+    bases, off = M.synth_reads(ix, seed=4242, n_reads=400_000, read_len=150)
+    return ix, bases, off
+
+
+def test_full_size_properties(medium, tmp_path):
+    """size-independent properties at a batch the oracle cannot finish in seconds:
+    idempotence, shard invariance (two halves == whole: the multi-GPU read sharding), strand
+    symmetry (reverse-complemented reads give the same hits with the strands swapped), and a
+    sampled bit-exact comparison with the oracle."""
+    ix, bases, off = medium
+    n = len(off) - 1
+    whole = ix.bin_batch(bases, off, device=0)
+    again = ix.bin_batch(bases, off, device=0)
+    assert_same_hits(whole, again)
+    assert len(whole) > 0.8 * n
+    # shards
+    h = n // 2
+    a = ix.bin_batch(bases[: h * 150], off[: h + 1], device=0)
+    b = ix.bin_batch(bases[h * 150:], off[h:] - off[h], device=0)
+    b["read"] += h
+    assert_same_hits(np.concatenate([a, b]), whole)
+    # strand symmetry
+    comp = np.full(256, ord("N"), np.uint8)
+    for x, y in zip(b"ACGTacgt", b"TGCATGCA"):
+        comp[x] = y
+    rc = comp[bases.reshape(n, 150)[:, ::-1]].reshape(-1)
+    r = ix.bin_batch(rc, off, device=0)
+    key = lambda hh, flip: set(zip(hh["read"].tolist(), hh["tax_id"].tolist(), hh["gi"].tolist(), hh["edit"].tolist(),
+                                   hh["offset"].tolist(), (hh["strand"] ^ flip).tolist()))
+    assert key(whole, 0) == key(r, 1)
+    # sampled oracle comparison
+    p = str(tmp_path / "m.idx")
+    ix.write(p)
+    ns = 4000
+    want, _ = O.Index.read(p).bin_batch(bases[: ns * 150], off[: ns + 1], threads=8)
+    assert_same_hits(whole[whole["read"] < ns], want)
