@@ -1,0 +1,435 @@
+// mtsv-binner -- drop-in command line of the reference binary (src/bin/mtsv-binner.rs) over
+// libmtsv_amd: same flags and defaults (:26-113), same validation (:140-262), same exit codes
+// (0 ok, 2 query error, 3 no results path, 4 resume error, 11 write error, 12 read error;
+// invalid numbers abort like the reference's panics, exit 101), same results grammar
+// (src/binner.rs:310-379), same resume rule (:347-411).  Extras: --device, --batch-reads.
+// The reads of a batch are processed on the GPU; result lines are written in input order (the
+// reference's order is unspecified: vendor/cue/src/lib.rs:67-74).
+#include <zlib.h>
+
+#include <cerrno>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+#include <string>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/mtsv_amd.h"
+
+namespace {
+
+bool g_verbose = false;
+void logmsg(const char* level, const std::string& msg) {
+    if (!g_verbose && !strcmp(level, "DEBUG")) return;
+    char ts[32];
+    time_t t = time(nullptr);
+    strftime(ts, sizeof ts, "%Y-%m-%d %H:%M:%S", localtime(&t));
+    printf("[%s %s mtsv_binner] %s\n", level, ts, msg.c_str());  // util.rs:10-24: stdout
+    fflush(stdout);
+}
+[[noreturn]] void panic(const std::string& msg) {  // the reference's expect()/panic!() paths
+    fprintf(stderr, "thread 'main' panicked: %s\n", msg.c_str());
+    exit(101);
+}
+
+// open_maybe_gz (binner.rs:21-33): gzip magic sniff; zlib reads both transparently
+struct Input {
+    gzFile f = nullptr;
+    std::vector<char> buf;
+    size_t pos = 0, len = 0;
+    bool eof = false;
+    bool open(const std::string& path) {
+        f = gzopen(path.c_str(), "rb");
+        if (!f) return false;
+        gzbuffer(f, 1 << 20);
+        buf.resize(1 << 20);
+        return true;
+    }
+    ~Input() {
+        if (f) gzclose(f);
+    }
+    // returns false at EOF with no data; sets *err on a read error
+    bool getline(std::string& out, bool* err) {
+        out.clear();
+        for (;;) {
+            if (pos == len) {
+                if (eof) return !out.empty();
+                int n = gzread(f, buf.data(), (unsigned)buf.size());
+                if (n < 0) {
+                    *err = true;
+                    return false;
+                }
+                if (n == 0) {
+                    eof = true;
+                    return !out.empty();
+                }
+                pos = 0;
+                len = (size_t)n;
+            }
+            char* nl = (char*)memchr(buf.data() + pos, '\n', len - pos);
+            if (nl) {
+                out.append(buf.data() + pos, nl - (buf.data() + pos));
+                pos = nl - buf.data() + 1;
+                if (!out.empty() && out.back() == '\r') out.pop_back();
+                return true;
+            }
+            out.append(buf.data() + pos, len - pos);
+            pos = len;
+        }
+    }
+};
+
+struct Record {
+    std::string id, seq;
+};
+
+// bio::io::{fasta,fastq} readers as used at binner.rs:169-199; id = first token of the header
+struct FastxReader {
+    Input in;
+    bool fastq;
+    std::string pending;  // a header line already consumed (FASTA)
+    bool have_pending = false;
+    bool error = false;
+    std::string err_msg;
+
+    static std::string first_token(const std::string& h) {
+        size_t e = h.find_first_of(" \t", 1);
+        return h.substr(1, e == std::string::npos ? std::string::npos : e - 1);
+    }
+    bool next(Record& r) {
+        std::string line;
+        bool ioerr = false;
+        if (fastq) {
+            do {
+                if (!in.getline(line, &ioerr)) {
+                    if (ioerr) fail("read error");
+                    return false;
+                }
+            } while (line.empty());
+            if (line[0] != '@') return fail("Expected @ at record start.");
+            r.id = first_token(line);
+            r.seq.clear();
+            for (;;) {
+                if (!in.getline(line, &ioerr)) return fail("Incomplete record.");
+                if (!line.empty() && line[0] == '+') break;
+                r.seq += line;
+            }
+            size_t q = 0;
+            while (q < r.seq.size()) {
+                if (!in.getline(line, &ioerr)) return fail("Incomplete record.");
+                q += line.size();
+            }
+            if (r.seq.empty()) in.getline(line, &ioerr);  // empty quality line of an empty read
+            if (q != r.seq.size() && !r.seq.empty()) return fail("Unequal length of sequence an qualities.");
+            return true;
+        }
+        if (!have_pending) {
+            do {
+                if (!in.getline(line, &ioerr)) {
+                    if (ioerr) fail("read error");
+                    return false;
+                }
+            } while (line.empty());
+            pending = line;
+        }
+        have_pending = false;
+        if (pending.empty() || pending[0] != '>') return fail("Expected > at record start.");
+        r.id = first_token(pending);
+        r.seq.clear();
+        while (in.getline(line, &ioerr)) {
+            if (!line.empty() && line[0] == '>') {
+                pending = line;
+                have_pending = true;
+                break;
+            }
+            r.seq += line;
+        }
+        if (ioerr) return fail("read error");
+        return true;
+    }
+    bool fail(const char* m) {
+        error = true;
+        err_msg = m;
+        return false;
+    }
+};
+
+// resume_offset_from_results (mtsv-binner.rs:366-396): index of the last input record whose id
+// appears in the results file, plus one
+int resume_offset(const std::string& results, const std::string& input, bool fastq, uint64_t* off) {
+    FILE* f = fopen(results.c_str(), "rb");
+    if (!f) return -1;
+    std::unordered_set<std::string> ids;
+    std::string line;
+    char buf[1 << 16];
+    auto flush_line = [&](std::string& l) -> bool {
+        size_t a = l.find_first_not_of(" \t\r\n");
+        if (a != std::string::npos) {
+            size_t c = l.rfind(':');
+            if (c == std::string::npos || c == 0) return false;  // "Missing read id"
+            ids.insert(l.substr(0, c));
+        }
+        l.clear();
+        return true;
+    };
+    while (fgets(buf, sizeof buf, f)) {
+        line += buf;
+        if (!line.empty() && line.back() == '\n') {
+            line.pop_back();
+            if (!flush_line(line)) {
+                fclose(f);
+                return -1;
+            }
+        }
+    }
+    if (!line.empty() && !flush_line(line)) {
+        fclose(f);
+        return -1;
+    }
+    fclose(f);
+    FastxReader rd;
+    rd.fastq = fastq;
+    if (!rd.in.open(input)) return -1;
+    Record r;
+    uint64_t idx = 0, last = 0;
+    bool any = false;
+    while (rd.next(r)) {
+        if (ids.count(r.id)) {
+            last = idx;
+            any = true;
+        }
+        idx++;
+    }
+    if (rd.error) return -1;
+    *off = any ? last + 1 : 0;
+    return 0;
+}
+
+struct Args {
+    std::string fasta, fastq, index, results, output_format = "default";
+    std::string threads = "4", edit = "0.13", seed_size = "18", seed_interval = "15", min_seed = "0.015",
+                max_hits = "2000", tune_max_hits = "200", max_assign, max_cand, read_offset = "0";
+    bool verbose = false, force = false;
+    int device = 0;
+    uint64_t batch_reads = 1u << 20;
+};
+
+[[noreturn]] void usage_error(const std::string& m) {
+    fprintf(stderr, "error: %s\n\nUSAGE:\n    mtsv-binner [FLAGS] [OPTIONS] --index <INDEX> <--fasta <FASTA>|--fastq <FASTQ>>\n", m.c_str());
+    exit(1);  // clap usage errors
+}
+
+uint64_t parse_usize(const std::string& s, const char* what) {
+    if (s.empty()) panic(what);
+    char* e = nullptr;
+    errno = 0;
+    if (s[0] == '-') panic(what);
+    unsigned long long v = strtoull(s.c_str(), &e, 10);
+    if (*e || errno) panic(what);
+    return v;
+}
+double parse_f64(const std::string& s, const char* what) {
+    char* e = nullptr;
+    if (s.empty()) panic(what);
+    double v = strtod(s.c_str(), &e);
+    if (*e) panic(what);
+    return v;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    Args a;
+    for (int i = 1; i < argc; i++) {
+        std::string k = argv[i];
+        auto val = [&]() -> std::string {
+            size_t eq = k.find('=');
+            if (k.rfind("--", 0) == 0 && eq != std::string::npos) {
+                std::string v = k.substr(eq + 1);
+                k = k.substr(0, eq);
+                return v;
+            }
+            if (i + 1 >= argc) usage_error("The argument '" + k + "' requires a value but none was supplied");
+            return argv[++i];
+        };
+        std::string key = k.substr(0, k.find('='));
+        if (key == "--fasta") a.fasta = val();
+        else if (key == "--fastq") a.fastq = val();
+        else if (key == "-i" || key == "--index") a.index = val();
+        else if (key == "-m" || key == "--results") a.results = val();
+        else if (key == "-t" || key == "--threads") a.threads = val();
+        else if (key == "-e" || key == "--edit-rate") a.edit = val();
+        else if (key == "--seed-size") a.seed_size = val();
+        else if (key == "--seed-interval") a.seed_interval = val();
+        else if (key == "--min-seed") a.min_seed = val();
+        else if (key == "--max-hits") a.max_hits = val();
+        else if (key == "--tune-max-hits") a.tune_max_hits = val();
+        else if (key == "--max-assignments") a.max_assign = val();
+        else if (key == "--max-candidates") a.max_cand = val();
+        else if (key == "--read-offset") a.read_offset = val();
+        else if (key == "--output-format") a.output_format = val();
+        else if (key == "--force-overwrite") a.force = true;
+        else if (key == "-v") a.verbose = true;
+        else if (key == "--device") a.device = atoi(val().c_str());
+        else if (key == "--batch-reads") a.batch_reads = strtoull(val().c_str(), nullptr, 10);
+        else if (key == "-h" || key == "--help") {
+            printf("mtsv-binner (MI355X) -- flags as the reference: --fasta|--fastq, -i/--index, -m/--results, -t/--threads,\n"
+                   "-e/--edit-rate, --seed-size, --seed-interval, --min-seed, --max-hits, --tune-max-hits, --max-assignments,\n"
+                   "--max-candidates, --read-offset, --output-format default|long, --force-overwrite, -v; extras: --device N, --batch-reads N\n");
+            return 0;
+        } else if (key == "-V" || key == "--version") {
+            printf("mtsv 2.1.0 (%s)\n", mtsv_version());
+            return 0;
+        } else
+            usage_error("Found argument '" + k + "' which wasn't expected, or isn't valid in this context");
+    }
+    if (a.fasta.empty() == a.fastq.empty())
+        usage_error(a.fasta.empty() ? "The following required arguments were not provided: --fasta <FASTA> | --fastq <FASTQ>"
+                                    : "The argument '--fasta <FASTA>' cannot be used with '--fastq <FASTQ>'");
+    if (a.index.empty()) usage_error("The following required arguments were not provided: --index <INDEX>");
+    if (a.output_format != "default" && a.output_format != "long")
+        usage_error("'" + a.output_format + "' isn't a valid value for '--output-format <OUTPUT_FORMAT>'");
+    g_verbose = a.verbose;
+
+    const bool fastq = a.fasta.empty();
+    const std::string input = fastq ? a.fastq : a.fasta;
+    (void)parse_usize(a.threads, "Invalid number entered for number of threads!");
+    mtsv_params p;
+    mtsv_params_default(&p);
+    p.edit_rate = parse_f64(a.edit, "Invalid edit proportion entered!");
+    logmsg("INFO", "Max Edit Tolerance Proportion: " + a.edit);
+    if (p.edit_rate < 0.0 || p.edit_rate > 1.0) panic("Edit tolerance proportion must be between 0 and 1, inclusive");
+    uint64_t seed_size = parse_usize(a.seed_size, "Invalid seed size entered!");
+    if (seed_size < 16) logmsg("WARN", "Seed size may be small enough that it causes performance issues.");
+    else if (seed_size > 24) logmsg("WARN", "Seed size may be large enough that significant results are ignored.");
+    uint64_t seed_gap = parse_usize(a.seed_interval, "Invalid seed interval entered!");
+    if (seed_gap < 2) logmsg("WARN", "Seed interval may be small enough that it causes performance issues.");
+    else if (seed_gap > 10) logmsg("WARN", "Seed interval may be large enough that significant results are ignored.");
+    p.min_seed = parse_f64(a.min_seed, "Invalid min seeds entered!");
+    if (p.min_seed <= 0.0 || p.min_seed > 1.0) panic("Min seed percent must be between 0 and 1");
+    p.max_hits = parse_usize(a.max_hits, "Invalid cutoff for max hits!");
+    p.tune_max_hits = parse_usize(a.tune_max_hits, "Invalid cutoff for max hits!");
+    p.max_assignments = a.max_assign.empty() ? -1 : (int64_t)parse_usize(a.max_assign, "Invalid number entered for max assignments!");
+    p.max_candidates = a.max_cand.empty() ? -1 : (int64_t)parse_usize(a.max_cand, "Invalid number entered for max candidates!");
+    uint64_t read_offset = parse_usize(a.read_offset, "Invalid read offset entered!");
+    if (seed_size == 0 || seed_size > 0xffffffffull || seed_gap == 0 || seed_gap > 0xffffffffull)
+        panic("seed size / interval out of range");  // the reference panics on a zero step (itertools)
+    p.seed_size = (uint32_t)seed_size;
+    p.seed_interval = (uint32_t)seed_gap;
+    const bool long_fmt = a.output_format == "long";
+
+    if (a.results.empty()) {
+        logmsg("ERROR", "No results path provided!");
+        return 3;
+    }
+    FILE* probe = fopen(a.results.c_str(), "rb");
+    const bool exists = probe != nullptr;
+    if (probe) fclose(probe);
+    const bool append = !a.force && exists;
+    uint64_t resume = 0;
+    if (a.force) {
+        logmsg("INFO", "Forcing overwrite of " + a.results);
+    } else if (exists) {
+        logmsg("INFO", "Existing results detected at " + a.results + "; resuming previous run.");
+        if (resume_offset(a.results, input, fastq, &resume) != 0) {
+            logmsg("ERROR", "Error computing resume offset");
+            return 4;
+        }
+        logmsg("INFO", "Resuming after read offset " + std::to_string(resume) + " from " + a.results);
+    }
+    read_offset += resume;
+
+    // get_fastx_and_write_matching_bin_ids (binner.rs:149-217)
+    FastxReader rd;
+    rd.fastq = fastq;
+    if (!rd.in.open(input)) {
+        logmsg("ERROR", "Error running query: cannot open " + input);
+        return 2;
+    }
+    FILE* out = fopen(a.results.c_str(), append ? "ab" : "wb");
+    if (!out) {
+        logmsg("ERROR", "Error running query: cannot open results file " + a.results);
+        return 2;
+    }
+    logmsg("INFO", "Deserializing candidate filter ...");
+    mtsv_index* ix = nullptr;
+    if (mtsv_index_load(a.index.c_str(), &ix) != MTSV_OK || mtsv_index_to_device(ix, a.device, MTSV_DEV_DEFAULT) != MTSV_OK) {
+        logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+        return 2;
+    }
+    logmsg("INFO", "Beginning queries.");
+    const clock_t t0 = clock();
+    struct timespec w0;
+    clock_gettime(CLOCK_MONOTONIC, &w0);
+
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off{0};
+    std::string ids;
+    std::vector<uint64_t> id_off{0};
+    Record r;
+    uint64_t skipped = 0, total = 0;
+    auto flush = [&]() -> int {
+        if (off.size() == 1) return 0;
+        mtsv_hit* hits = nullptr;
+        uint64_t nh = 0;
+        if (mtsv_bin_batch(ix, a.device, bases.data(), off.data(), off.size() - 1, &p, &hits, &nh) != MTSV_OK) {
+            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+            return 2;
+        }
+        char* text = nullptr;
+        uint64_t len = 0;
+        int rc = mtsv_format_results(hits, nh, ids.data(), id_off.data(), off.size() - 1, long_fmt, &text, &len);
+        mtsv_hits_free(hits);
+        if (rc != MTSV_OK) {
+            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+            return 2;
+        }
+        bool ok = len == 0 || fwrite(text, 1, len, out) == len;
+        mtsv_free(text);
+        if (!ok) {
+            logmsg("ERROR", "Error writing to result file");
+            return 11;
+        }
+        total += off.size() - 1;
+        logmsg("DEBUG", "taxonomic binning: " + std::to_string(total) + " reads done");
+        bases.clear();
+        off.assign(1, 0);
+        ids.clear();
+        id_off.assign(1, 0);
+        return 0;
+    };
+    while (rd.next(r)) {
+        if (skipped < read_offset) {
+            skipped++;
+            continue;
+        }
+        bases.insert(bases.end(), r.seq.begin(), r.seq.end());
+        off.push_back(bases.size());
+        ids += r.id;
+        ids.push_back('\0');
+        id_off.push_back(ids.size());
+        if (off.size() - 1 >= a.batch_reads || bases.size() >= (1ull << 30)) {
+            if (int rc = flush()) return rc;
+        }
+    }
+    if (rd.error) {
+        logmsg("ERROR", "Unable to read from input file: " + rd.err_msg);
+        return 12;  // binner.rs:81-84
+    }
+    if (int rc = flush()) return rc;
+    if (fclose(out) != 0) {
+        logmsg("ERROR", "Error writing to result file");
+        return 11;
+    }
+    struct timespec w1;
+    clock_gettime(CLOCK_MONOTONIC, &w1);
+    (void)t0;
+    char msg[160];
+    snprintf(msg, sizeof msg, "All worker and result consumer threads terminated. Took %.3f seconds.",
+             (w1.tv_sec - w0.tv_sec) + (w1.tv_nsec - w0.tv_nsec) * 1e-9);
+    logmsg("INFO", msg);
+    mtsv_index_free(ix);
+    return 0;
+}

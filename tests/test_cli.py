@@ -1,0 +1,90 @@
+"""The drop-in command line (mtsv_tools_amd/bin/mtsv-binner): flags, exit codes and -- on a GPU --
+byte-identical result lines for FASTA, FASTQ and gzip input, read offset and resume."""
+import gzip
+import os
+import subprocess
+
+import pytest
+
+import mtsv_tools_amd as M
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mtsv_tools_amd", "bin", "mtsv-binner")
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def run(*args):
+    return subprocess.run([BIN, *args], capture_output=True, text=True, timeout=600)
+
+
+def test_exit_codes_without_touching_the_gpu(tmp_path):
+    assert run("--fasta", "x").returncode == 1                                  # clap: missing --index
+    assert run("--fasta", "x", "--fastq", "y", "-i", "z").returncode == 1      # conflicting inputs
+    assert run("--fasta", "x", "-i", "y").returncode == 3                      # no results path (mtsv-binner.rs:264)
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "-e", "1.5").returncode == 101   # panic!: edit rate
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--min-seed", "0").returncode == 101
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--seed-size", "abc").returncode == 101
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--output-format", "xml").returncode == 1
+    assert run("--fasta", str(tmp_path / "missing.fa"), "-i", "y", "-m", str(tmp_path / "r")).returncode == 2
+    assert "2.1.0" in run("--version").stdout
+
+
+def _golden_inputs(tmp_path):
+    reads = [l.rstrip("\n") for l in open(os.path.join(GOLD, "e2e_reads.txt"), encoding="latin-1")]
+    fa, fq = tmp_path / "reads.fasta", tmp_path / "reads.fastq"
+    with open(fa, "w", encoding="latin-1") as f:
+        for i, r in enumerate(reads):
+            f.write(f">r{i} some description\n")
+            for k in range(0, len(r), 60):      # multi-line FASTA
+                f.write(r[k:k + 60] + "\n")
+    with open(fq, "w", encoding="latin-1") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@r{i} desc\n{r}\n+\n{'I' * len(r)}\n")
+    fqgz = tmp_path / "reads.fastq.gz"
+    with open(fq, "rb") as src, gzip.open(fqgz, "wb") as dst:
+        dst.write(src.read())
+    idx = tmp_path / "db.idx"
+    M.MGIndex.build_fasta(os.path.join(GOLD, "e2e_db.fasta"), threads=4).write(str(idx))
+    return reads, str(fa), str(fq), str(fqgz), str(idx)
+
+
+@pytest.mark.gpu
+def test_cli_end_to_end_matches_golden_results(tmp_path):
+    reads, fa, fq, fqgz, idx = _golden_inputs(tmp_path)
+    want = sorted(open(os.path.join(GOLD, "e2e_default.results")).read().splitlines())
+    want_long = sorted(open(os.path.join(GOLD, "e2e_default_long.results")).read().splitlines())
+    stress = sorted(open(os.path.join(GOLD, "e2e_stress.results")).read().splitlines())
+    for flag, path in (("--fasta", fa), ("--fastq", fq), ("--fastq", fqgz)):
+        out = tmp_path / "res.txt"
+        r = run(flag, path, "-i", idx, "-m", str(out), "--force-overwrite", "--batch-reads", "50")
+        assert r.returncode == 0, r.stdout + r.stderr
+        assert sorted(open(out).read().splitlines()) == want
+    out = tmp_path / "long.txt"
+    assert run("--fasta", fa, "-i", idx, "-m", str(out), "--output-format", "long").returncode == 0
+    assert sorted(open(out).read().splitlines()) == want_long
+    out = tmp_path / "stress.txt"
+    assert run("--fastq", fq, "-i", idx, "-m", str(out), "--max-hits", "5", "--tune-max-hits", "2", "--max-candidates", "3",
+               "--max-assignments", "1", "--min-seed", "0.5").returncode == 0
+    assert sorted(open(out).read().splitlines()) == stress
+
+
+@pytest.mark.gpu
+def test_cli_read_offset_and_resume(tmp_path):
+    reads, fa, fq, fqgz, idx = _golden_inputs(tmp_path)
+    want = open(os.path.join(GOLD, "e2e_default.results")).read().splitlines()
+    ids = [int(l.split(":")[0][1:]) for l in want]
+    out = tmp_path / "off.txt"
+    assert run("--fasta", fa, "-i", idx, "-m", str(out), "--read-offset", "100").returncode == 0
+    assert sorted(open(out).read().splitlines()) == sorted(l for l, i in zip(want, ids) if i >= 100)
+    # resume (mtsv-binner.rs:347-411): an existing results file holding the lines of the first 120 reads
+    part = tmp_path / "resume.txt"
+    with open(part, "w") as f:
+        f.write("".join(l + "\n" for l, i in zip(want, ids) if i < 120))
+    last = max(i for i in ids if i < 120)
+    assert run("--fastq", fq, "-i", idx, "-m", str(part)).returncode == 0
+    got = open(part).read().splitlines()
+    assert sorted(got) == sorted([l for l, i in zip(want, ids) if i < 120] + [l for l, i in zip(want, ids) if i > last])
+    # a results file without a read id is a resume error (exit 4)
+    bad = tmp_path / "bad.txt"
+    bad.write_text("no colon here\n")
+    assert run("--fasta", fa, "-i", idx, "-m", str(bad)).returncode == 4
