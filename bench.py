@@ -11,6 +11,7 @@ scaling: every rank processes its own batch of the same size).  Rank 0 prints ON
 
 Workloads (BASELINE.json configs; generators of SURVEY.md 8(d), seeds fixed):
     config1  1M x 150 bp reads vs "1 GB MG-index"  (n = 2.76e8 symbols, 256 taxa x 4 GIs x 270 kb)
+    config2  10M x 150 bp reads vs "10 GB MG-index" (n = 2.76e9)  -- several minutes of host-side index build
     config0  10k x 100 bp reads vs "1 MB MG-index" (n = 2.8e5)  -- plumbing / quick check
 """
 import argparse
@@ -29,6 +30,7 @@ WORKLOADS = {
     "config0": (8, 2, 17500, 10_000, 100, "10k x 100bp reads vs 1MB MG-index (n=2.8e5)"),
     "config1": (256, 4, 270_000, 1_000_000, 150, "1M x 150bp reads vs 1GB MG-index (n=2.76e8)"),
     "quarter": (64, 4, 270_000, 1_000_000, 150, "1M x 150bp reads vs 250MB MG-index (n=6.9e7)"),
+    "config2": (1024, 4, 674_000, 10_000_000, 150, "10M x 150bp reads vs 10GB MG-index (n=2.76e9)"),
 }
 SEED_DB = 0x6D747376
 PEAK_HBM_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
@@ -57,6 +59,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (the box's CPU share of one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verify-mode", type=int, default=0, help="0: reference order (SW + edit per candidate), 1: edit first")
     ap.add_argument("--dev-flags", type=int, default=0, help="MTSV_DEV_* flags (1: sampled SA only, 2: no k-mer table)")
     args = ap.parse_args()
 
@@ -112,6 +115,7 @@ def main():
     bases, off = M.synth_reads(ix, seed=1000 + rank, n_reads=n_reads, read_len=read_len)
     params = M.default_params()
     batch = M.Batch(ix, local_rank, n_reads, len(bases))
+    batch.set_verify_mode(args.verify_mode)
     t0 = time.time()
     batch.upload(bases, off)
     t_h2d = time.time() - t0
@@ -143,11 +147,25 @@ def main():
     pcie_rate = None
     if batch_pcie is not None:
         t0 = time.perf_counter()
+        batch_pcie.set_verify_mode(args.verify_mode)
         batch_pcie.upload(bases, off)
         batch_pcie.run(params)
         batch_pcie.download()
         pcie_rate = n_reads / (time.perf_counter() - t0)
         batch_pcie.close()
+    # the other evaluation order of the two acceptance predicates, for information (never `value`)
+    alt = None
+    if rank == 0:
+        other = 1 - args.verify_mode
+        batch.set_verify_mode(other)
+        batch.run(params)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            batch.run(params)
+        alt_hits = batch.download()
+        alt = {"verify_mode": ["reference", "edit_first"][other], "reads_per_s": 3 * n_reads / (time.perf_counter() - t1),
+               "stage_ms": batch.stats()["stage_ms"],
+               "hits_identical_to_timed_mode": bool(len(alt_hits) == len(hits) and all(np.array_equal(alt_hits[f], hits[f]) for f in ("read", "tax_id", "gi", "edit", "strand", "offset")))}
 
     if rank != 0:
         if world > 1:
@@ -234,6 +252,7 @@ def main():
         "config": {"workload": f"{args.workload}: {desc}", "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                    "index_symbols": info["n"], "index_file_bytes": os.path.getsize(idx_path),
                    "index_hbm_bytes": info["device_bytes"], "dev_flags": args.dev_flags,
+                   "verify_mode": ["reference (SW prefilter + edit distance per verified candidate)", "edit_first"][args.verify_mode],
                    "parallelism": f"reads sharded x{world}, index replicated, no collective"},
         "roofline": roof,
         "cpu_baseline": cpu,
@@ -243,6 +262,7 @@ def main():
                                                 "n_verified", "window_bytes", "n_hits", "n_passes")},
         "parity": parity,
         "pcie_inclusive_reads_per_s": pcie_rate,
+        "other_verify_order": alt,
         "setup_s": {"index_build": t_build, "index_load": t_load, "index_pack_upload_accel": t_upload,
                     "reads_h2d": t_h2d},
     }

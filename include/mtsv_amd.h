@@ -136,6 +136,14 @@ void mtsv_hits_free(mtsv_hit *hits);
  * on `hip_device`.  max_hits_ws = seed-hit workspace entries (0 = default). */
 int mtsv_batch_create(mtsv_index *ix, int hip_device, uint64_t max_reads, uint64_t max_bases,
                       uint64_t max_hits_ws, mtsv_batch **out);
+/* Order in which the two acceptance predicates of index.rs:406,410 are evaluated (results identical):
+ *   MTSV_VERIFY_REFERENCE   SW prefilter score and edit distance for every verified candidate (default)
+ *   MTSV_VERIFY_EDIT_FIRST  edit distance first; for reads <= 253 bases edits <= ED implies the SW
+ *                           threshold, so the SW sweep is not needed (longer reads use REFERENCE)
+ * The environment variable MTSV_VERIFY=reference|edit_first sets the default of new batches. */
+#define MTSV_VERIFY_REFERENCE 0
+#define MTSV_VERIFY_EDIT_FIRST 1
+int mtsv_batch_set_verify_mode(mtsv_batch *b, int mode);
 int mtsv_batch_upload(mtsv_batch *b, const uint8_t *bases, const uint64_t *read_off,
                       uint64_t n_reads);
 int mtsv_batch_run(mtsv_batch *b, const mtsv_params *params); /* synchronous: returns when done */

@@ -58,7 +58,7 @@ EXPORTS = [
     "mtsv_index_load", "mtsv_index_build", "mtsv_index_build_fasta", "mtsv_index_write",
     "mtsv_index_info", "mtsv_index_free", "mtsv_index_to_device", "mtsv_bin_batch",
     "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run",
-    "mtsv_batch_stats_get", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
+    "mtsv_batch_stats_get", "mtsv_batch_set_verify_mode", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads",
 ]
 
@@ -93,6 +93,7 @@ def lib():
         L.mtsv_batch_create.argtypes = [vp, i32, u64, u64, u64, C.POINTER(vp)]
         L.mtsv_batch_upload.argtypes = [vp, vp, vp, u64]
         L.mtsv_batch_run.argtypes = [vp, C.POINTER(Params)]
+        L.mtsv_batch_set_verify_mode.argtypes = [vp, i32]
         L.mtsv_batch_stats_get.argtypes = [vp, C.POINTER(BatchStats)]
         L.mtsv_batch_download.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
         L.mtsv_batch_free.argtypes = [vp]
@@ -223,6 +224,9 @@ class Batch:
         read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
         _check(lib().mtsv_batch_upload(self.h, bases.ctypes.data, read_off.ctypes.data,
                                        len(read_off) - 1))
+
+    def set_verify_mode(self, mode):
+        _check(lib().mtsv_batch_set_verify_mode(self.h, mode))
 
     def run(self, params=None):
         params = params or default_params()

@@ -3,6 +3,7 @@
 // large HBM-resident batches: reads stay on the device between stages, every stage is one launch
 // over the whole batch, and the only host round-trips are two 8-byte totals per pass.
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 #include <vector>
@@ -57,6 +58,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_worklist2, hit_cap, &bytes);
     dev_alloc(&d_hits, hits_cap, &bytes);
     HIP_CHECK(hipHostMalloc((void**)&h_counters, 8 * sizeof(uint64_t)));
+    if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
 }
 
@@ -199,7 +201,10 @@ void Batch::run(const mtsv_params& p) {
                 a.wl_count = cur_cnt;
                 a.worklist_next = nxt;
                 a.wl_next_count = nxt_cnt;
-                launch_evaluate(stream, v, a, upper, max_len);
+                if (verify_mode == 1 && max_len <= 253)
+                    launch_edit_myers(stream, v, a, upper, max_len);
+                else
+                    launch_evaluate(stream, v, a, upper, max_len);
                 HIP_CHECK(hipMemcpyAsync(h_counters, nxt_cnt, 4, hipMemcpyDeviceToHost, stream));
                 HIP_CHECK(hipStreamSynchronize(stream));
                 const uint32_t n_next = *(const uint32_t*)h_counters;

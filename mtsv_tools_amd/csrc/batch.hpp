@@ -33,6 +33,7 @@ struct Batch {
 
     std::vector<uint32_t> h_read_off;
     uint32_t max_len = 0;
+    int verify_mode = 0;  // 0 = reference order (SW + edit per candidate), 1 = edit first (MTSV_VERIFY_EDIT_FIRST)
     uint64_t n_reads = 0;
     uint64_t n_hits_total = 0;
     mtsv_batch_stats stats{};

@@ -203,6 +203,12 @@ int mtsv_batch_download(mtsv_batch* b, mtsv_hit** hits, uint64_t* n_hits) {
     GUARD(b->impl.download(hits, n_hits))
 }
 
+int mtsv_batch_set_verify_mode(mtsv_batch* b, int mode) {
+    if (!b || (mode != MTSV_VERIFY_REFERENCE && mode != MTSV_VERIFY_EDIT_FIRST)) return fail_arg("bad verify mode");
+    b->impl.verify_mode = mode;
+    return MTSV_OK;
+}
+
 void mtsv_batch_free(mtsv_batch* b) { delete b; }
 
 int mtsv_bin_batch(mtsv_index* ix, int hip_device, const uint8_t* bases, const uint64_t* read_off, uint64_t n_reads,

@@ -865,6 +865,104 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Alternative verification order ("edit first"): acceptance is the conjunction of two pure
+// predicates, SW >= L - 2*ED and edits <= ED (index.rs:406,410), and for reads up to 253 bases the
+// SW score is the exact local score, for which edits <= ED implies SW >= L - 2*ED (an alignment with
+// e edits scores >= L - 2e; tests/test_oracle.py).  So for such reads edits <= ED alone decides.
+// k_edit_myers computes Aligner::min_edit_distance (align.rs:28-85: first row 0, answer = min of
+// the last row) with Myers' bit-vector recurrence, one lane per candidate, W 64-bit words per
+// column.  Read 'N' matches nothing (index.rs:272-279), reference 'N' matches nothing either.
+// ---------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a) {
+    const uint32_t n_work = *a.wl_count;
+    const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
+                                               : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    unsigned long long verified = 0, wbytes = 0;
+    for (uint32_t w = tid; w < n_work; w += stride) {
+        const uint32_t g = a.worklist[w];
+        const uint4 c = a.cand[g];
+        const uint32_t rs = a.cand_rs[g];
+        const DevBin bin = ix.bins[c.z];
+        const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
+        const uint32_t b0 = a.read_off[r_];
+        const uint32_t L = a.read_off[r_ + 1] - b0;
+        const uint32_t ED = (uint32_t)ceil((double)L * a.edit_rate);
+        const bool thr_wrapped = 2ull * ED > (uint64_t)L;
+        const uint8_t* read = a.bases + b0;
+        uint64_t eqA[W], eqC[W], eqG[W], eqT[W], Pv[W], Mv[W];
+#pragma unroll
+        for (int k = 0; k < W; k++) {
+            eqA[k] = eqC[k] = eqG[k] = eqT[k] = 0;
+            Pv[k] = ~0ull;
+            Mv[k] = 0;
+            for (uint32_t b = 0; b < 64; b++) {
+                uint32_t p = k * 64 + b;
+                if (p >= L) break;
+                uint32_t code = strand_code(read, L, strand, p);
+                uint64_t bit = 1ull << b;
+                eqA[k] |= code == 0 ? bit : 0;
+                eqC[k] |= code == 1 ? bit : 0;
+                eqG[k] |= code == 2 ? bit : 0;
+                eqT[k] |= code == 3 ? bit : 0;
+            }
+        }
+        const uint32_t Wn = c.y - c.x;
+        const int last_blk = (int)((L - 1) / 64);
+        const uint32_t last_bit = (L - 1) & 63;
+        int score = (int)L, best = (int)L;  // D[L][0] = L
+        for (uint32_t j = 0; j < Wn; j++) {
+            const uint32_t pos = c.x + j;
+            const uint32_t tc = pos < ix.n ? ix.text[pos] : 7u;
+            int hin = 0;  // first row is all zeros: no horizontal delta enters block 0
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                if (k > last_blk) break;
+                uint64_t Eq = tc == 0 ? eqA[k] : tc == 1 ? eqC[k] : tc == 2 ? eqG[k] : tc == 3 ? eqT[k] : 0ull;
+                const uint64_t pv = Pv[k], mv = Mv[k];
+                const uint64_t Xv = Eq | mv;
+                if (hin < 0) Eq |= 1ull;
+                const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                uint64_t Ph = mv | ~(Xh | pv);
+                uint64_t Mh = pv & Xh;
+                if (k == last_blk) score += (int)((Ph >> last_bit) & 1) - (int)((Mh >> last_bit) & 1);
+                const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
+                Ph <<= 1;
+                Mh <<= 1;
+                if (hin < 0) Mh |= 1ull;
+                else if (hin > 0) Ph |= 1ull;
+                Pv[k] = Mh | ~(Xv | Ph);
+                Mv[k] = Ph & Xv;
+                hin = hout;
+            }
+            best = min(best, score);
+        }
+        verified++;
+        wbytes += Wn;
+        const uint32_t ed = (uint32_t)best;
+        const bool pass = !thr_wrapped && ed <= ED;
+        if (pass) {
+            a.out[g] = make_uint4(bin.tax_id, bin.gi, c.x >= bin.start ? c.x - bin.start : 0, ed);
+            a.cand_status[g] = 2;
+        } else {
+            a.cand_status[g] = 1;
+            const uint32_t nxt = a.cand_next[g];
+            if (nxt != 0xffffffffu && nxt < maxc) a.worklist_next[atomicAdd(a.wl_next_count, 1u)] = a.strand_off[rs] + nxt;
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        verified += __shfl_down(verified, d);
+        wbytes += __shfl_down(wbytes, d);
+    }
+    if (lane_id() == 0 && verified) {
+        atomicAdd(a.n_verified, verified);
+        atomicAdd(a.window_bytes, wbytes);
+    }
+}
+
 // The ordered selection loop of index.rs:384-428 over the verified statuses: a candidate is in
 // status "pass" only if every earlier candidate of its TaxId failed, so the duplicate-TaxId skip
 // has already been applied; what remains are the two cut-offs and the rank order of the hits.
@@ -994,6 +1092,17 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
         else EVAL_CASE(32, true);
     }
 #undef EVAL_CASE
+}
+
+void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
+    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256), 256 * 8));
+    uint32_t W = (max_len + 63) / 64;
+#define MYERS_CASE(WW) hipLaunchKernelGGL(k_edit_myers<WW>, dim3(blocks), dim3(256), 0, s, ix, a)
+    if (W <= 1) MYERS_CASE(1);
+    else if (W <= 2) MYERS_CASE(2);
+    else if (W <= 3) MYERS_CASE(3);
+    else MYERS_CASE(4);
+#undef MYERS_CASE
 }
 
 void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,

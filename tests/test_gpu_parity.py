@@ -88,6 +88,24 @@ def test_adversarial_database_all_parameter_sets(tricky, pname, flags):
     assert_same_hits(got, want)
 
 
+@pytest.mark.parametrize("pname", list(PARAM_SETS))
+def test_edit_first_order_gives_identical_hits(tricky, pname):
+    """MTSV_VERIFY_EDIT_FIRST: Myers bit-vector edit distance decides (reads <= 253 bases); mixed
+    batches with longer reads fall back to the reference order.  Same hits either way."""
+    ix, orc, reads = tricky
+    mp, op = both_params(**PARAM_SETS[pname])
+    ix.to_device(0)
+    for subset in ([r for r in reads if len(r) <= 253], reads):
+        bases, off = helpers.reads_to_batch(subset)
+        want, _ = orc.bin_batch(bases, off, op, threads=8)
+        b = M.Batch(ix, 0, len(subset), len(bases))
+        b.set_verify_mode(1)
+        b.upload(bases, off)
+        b.run(mp)
+        assert_same_hits(b.download(), want)
+        b.close()
+
+
 def test_committed_golden_result_lines(tricky):
     """the committed end-to-end vectors (tests/golden/e2e_*.results) through the HIP path + the
     product's formatter"""
