@@ -9,6 +9,7 @@ A "step" is one pass of the whole hot path (seed search -> locate -> coalesce ->
 replicated per GPU and reads shard across ranks with no collective on the data path (weak
 scaling: every rank processes its own batch of the same size).  Rank 0 prints ONE JSON line.
 
+Default workload = the configuration BASELINE.json's metric is quoted on: config2.
 Workloads (BASELINE.json configs; generators of SURVEY.md 8(d), seeds fixed):
     config1  1M x 150 bp reads vs "1 GB MG-index"  (n = 2.76e8 symbols, 256 taxa x 4 GIs x 270 kb)
     config2  10M x 150 bp reads vs "10 GB MG-index" (n = 2.76e9)  -- several minutes of host-side index build
@@ -52,9 +53,9 @@ def algorithmic_bytes(ctr, n_reads):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("MTSV_BENCH_WORKLOAD", "config1"))
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default=os.environ.get("MTSV_BENCH_WORKLOAD", "config2"))
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (the box's CPU share of one GPU)")
@@ -97,10 +98,21 @@ def main():
 
     # ---- index: rank 0 builds + writes the MG-index file, every rank loads it (drop-in format) ----
     t0 = time.time()
+    index_cached = False
     if rank == 0:
-        ixb = M.MGIndex.synth(SEED_DB, n_taxa, gis, seq_len, threads=min(32, ncpu))  # host-side, untimed
-        ixb.write(idx_path)
-        ixb.close()
+        # the synthetic database is a pure function of (workload, SEED_DB): reuse a file left by an
+        # earlier run on this box (the loader re-validates every invariant of the file anyway)
+        expect_n = n_taxa * gis * seq_len + 1
+        try:
+            if os.path.exists(idx_path) and int.from_bytes(open(idx_path, "rb").read(8), "little") == expect_n:
+                index_cached = True
+        except OSError:
+            pass
+        if not index_cached:
+            ixb = M.MGIndex.synth(SEED_DB, n_taxa, gis, seq_len, threads=min(32, ncpu))  # host-side, untimed
+            ixb.write(idx_path + ".tmp")
+            ixb.close()
+            os.replace(idx_path + ".tmp", idx_path)
     t_build = time.time() - t0
     barrier()
     t0 = time.time()
@@ -263,7 +275,7 @@ def main():
         "parity": parity,
         "pcie_inclusive_reads_per_s": pcie_rate,
         "other_verify_order": alt,
-        "setup_s": {"index_build": t_build, "index_load": t_load, "index_pack_upload_accel": t_upload,
+        "setup_s": {"index_build": t_build, "index_file_reused": index_cached, "index_load": t_load, "index_pack_upload_accel": t_upload,
                     "reads_h2d": t_h2d},
     }
     print(json.dumps(out))

@@ -41,6 +41,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_strand_off, ns + 1, &bytes);
     dev_alloc(&d_strand_ncand, ns, &bytes);
     dev_alloc(&d_strand_nout, ns + 1, &bytes);
+    dev_alloc(&d_heavy_list, ns, &bytes);
     dev_alloc(&d_out_off, ns + 1, &bytes);
     dev_alloc(&d_tile_sums, (uint64_t)scan_tiles((uint32_t)ns) + 1, &bytes);
     dev_alloc(&d_counters, 8, &bytes);
@@ -69,7 +70,7 @@ Batch::~Batch() {
                     (void*)d_strand_nseeds, (void*)d_strand_off, (void*)d_strand_ncand, (void*)d_worklist,
                     (void*)d_strand_nout, (void*)d_out_off, (void*)d_tile_sums, (void*)d_counters, (void*)d_hit_row,
                     (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand, (void*)d_out,
-                    (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_worklist2})
+                    (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_worklist2, (void*)d_heavy_list})
         (void)hipFree(p);
     (void)hipHostFree(h_counters);
     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -172,8 +173,8 @@ void Batch::run(const mtsv_params& p) {
         HIP_CHECK(hipMemsetAsync(d_counters + 7, 0, 8, stream));
         launch_coalesce(stream, v, d_read_off, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, p.max_candidates, d_strand_off,
                         d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next, d_cand_rs,
-                        d_cand_status, d_strand_ncand, d_worklist, (uint32_t*)(d_counters + 1),
-                        (unsigned long long*)(d_counters + 3));
+                        d_cand_status, d_strand_ncand, d_worklist, (uint32_t*)(d_counters + 1), d_heavy_list,
+                        (uint32_t*)(d_counters + 1) + 1, (unsigned long long*)(d_counters + 3));
         HIP_CHECK(hipEventRecord(ev[5], stream));
         // ---- verify: rounds over the same-TaxId chains ----
         {

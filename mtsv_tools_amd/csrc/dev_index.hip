@@ -203,7 +203,7 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
     if (sentinel_row == UINT64_MAX) throw std::runtime_error("format: bwt holds no sentinel");
 
     // ---- text codes, SA samples, bins ---------------------------------------------------------
-    std::vector<uint8_t> codes(n);
+    std::vector<uint8_t> codes(((uint64_t)n + 3) / 4 * 4 + 16, (uint8_t)7);  // dword-padded for load16()
     parallel_ranges(n, threads, [&](uint64_t lo, uint64_t hi, int) {
         for (uint64_t i = lo; i < hi; i++) codes[i] = (uint8_t)sym_code(hx.text[i]);
     });
@@ -226,7 +226,7 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
     };
     up(&di->d_blocks, blocks.data(), (uint64_t)n_blocks * sizeof(RankBlock));
     up(&di->d_sa_sample, samp.data(), samp.size() * 4);
-    up(&di->d_text, codes.data(), n);
+    up(&di->d_text, codes.data(), codes.size());
     up(&di->d_bin_end, bin_end.data(), bin_end.size() * 4);
     up(&di->d_bins, bins.data(), bins.size() * sizeof(DevBin));
 

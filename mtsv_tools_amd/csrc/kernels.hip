@@ -376,44 +376,216 @@ __device__ inline void gstore(uint64_t* p, uint64_t v) {
 }
 __device__ inline void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-// bitonic network in its flip/disperse form: every comparator puts the minimum at the lower index,
-// so virtual +inf padding above n never moves and any n works.  Keys live in L2 (agent-scope
-// relaxed accesses bypass the per-CU L1); one wavefront owns the segment.
-__device__ void global_bitonic_sort(uint64_t* keys, uint32_t n) {
-    const uint32_t lane = lane_id();
+// ---------------------------------------------------------------------------------------------
+// Strands with more than 64 seed hits (repeats, N-run flanks: up to seeds x max_hits).  One
+// workgroup per strand; the three sorts (hits by (ref, q); candidates by (num_seeds desc, order);
+// candidates by (TaxId, rank)) run as a block-wide bitonic network on keys held in LDS.  Segments
+// that do not fit the LDS array fall back to one wavefront sorting in L2-resident scratch.
+// ---------------------------------------------------------------------------------------------
+constexpr uint32_t kHeavyKeys = 8192;  // 64 KiB of LDS
+
+template <bool BLK>
+struct KeyMem {
+    uint64_t* p;
+    __device__ uint64_t ld(uint32_t i) const { return BLK ? p[i] : gload(p + i); }
+    __device__ void st(uint32_t i, uint64_t v) const {
+        if (BLK) p[i] = v;
+        else gstore(p + i, v);
+    }
+    __device__ void sync() const {
+        if (BLK) __syncthreads();
+        else wave_mem_sync();
+    }
+    __device__ uint32_t tid() const { return BLK ? threadIdx.x : lane_id(); }
+    __device__ uint32_t nthreads() const { return BLK ? blockDim.x : (uint32_t)kWave; }
+};
+
+// flip/disperse bitonic network (every comparator ascending, so virtual +inf padding above n is inert)
+template <bool BLK>
+__device__ void big_sort(KeyMem<BLK> km, uint32_t n) {
+    const uint32_t tid = km.tid(), nt = km.nthreads();
     uint32_t np2 = 1;
     while (np2 < n) np2 <<= 1;
     const uint32_t half = np2 >> 1;
     for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t i = lane; i < half; i += kWave) {  // flip
-            uint32_t hk = k >> 1;
-            uint32_t blk = i / hk, pos = i % hk;
+        for (uint32_t i = tid; i < half; i += nt) {
+            uint32_t hk = k >> 1, blk = i / hk, pos = i % hk;
             uint32_t a = blk * k + pos, b = blk * k + k - 1 - pos;
             if (b < n) {
-                uint64_t x = gload(keys + a), y = gload(keys + b);
+                uint64_t x = km.ld(a), y = km.ld(b);
                 if (x > y) {
-                    gstore(keys + a, y);
-                    gstore(keys + b, x);
+                    km.st(a, y);
+                    km.st(b, x);
                 }
             }
         }
-        wave_mem_sync();
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {  // disperse
-            for (uint32_t i = lane; i < half; i += kWave) {
+        km.sync();
+        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
+            for (uint32_t i = tid; i < half; i += nt) {
                 uint32_t blk = i / j, pos = i % j;
                 uint32_t a = blk * 2 * j + pos, b = a + j;
                 if (b < n) {
-                    uint64_t x = gload(keys + a), y = gload(keys + b);
+                    uint64_t x = km.ld(a), y = km.ld(b);
                     if (x > y) {
-                        gstore(keys + a, y);
-                        gstore(keys + b, x);
+                        km.st(a, y);
+                        km.st(b, x);
                     }
                 }
             }
-            wave_mem_sync();
+            km.sync();
         }
     }
 }
+
+struct HeavyArgs {
+    const uint32_t* read_off;
+    uint32_t r0;
+    double edit_rate, min_seed;
+    uint32_t maxc;
+    const uint32_t* strand_off;
+    const uint32_t* strand_nseeds;
+    const uint32_t* hit_ref;
+    const uint32_t* hit_q;
+    uint64_t* hit_key;
+    uint64_t* cand_tmp;
+    uint4* cand;
+    uint32_t* cand_next;
+    uint32_t* cand_rs;
+    uint32_t* cand_status;
+    uint32_t* strand_ncand;
+    uint32_t* worklist;
+    uint32_t* wl_count;
+    unsigned long long* n_cand_total;
+};
+
+// BLK: called by every thread of the workgroup (contains barriers); !BLK: by one wavefront
+template <bool BLK>
+__device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_t rs, KeyMem<BLK> km, uint32_t* sh_nc) {
+    const uint32_t lane = lane_id();
+    const uint32_t tid = km.tid(), nt = km.nthreads();
+    const bool walker = !BLK || threadIdx.x < kWave;  // the sequential walk runs on one wavefront
+    const uint32_t o = a.strand_off[rs];
+    const uint32_t nh = a.strand_off[rs + 1] - o;
+    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, a.strand_nseeds[rs]);
+    for (uint32_t i = tid; i < nh; i += nt) km.st(i, ((uint64_t)a.hit_ref[o + i] << 32) | a.hit_q[o + i]);
+    km.sync();
+    big_sort(km, nh);  // seed_hits.sort(), index.rs:443
+    uint32_t nc = 0;
+    uint64_t* ct = a.cand_tmp + 2ull * o;
+    if (walker) {
+        Walk w{false, 0, 0, 0, 0};
+        for (uint32_t base = 0; base < nh; base += kWave) {
+            uint32_t cntv = min((uint32_t)kWave, nh - base);
+            uint32_t b = 0, ws = 0, we = 0;
+            bool ok = false;
+            if (lane < cntv) {
+                uint64_t key = km.ld(base + lane);
+                uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
+                b = min(find_bin(ix, site), ix.n_bins - 1);
+                DevBin bin = ix.bins[b];
+                ok = candidate_window(site, q, bin, g.L, g.ED, &ws, &we);
+            }
+            for (uint32_t i = 0; i < cntv; i++) {
+                uint32_t wsi = __builtin_amdgcn_readlane(ws, i), wei = __builtin_amdgcn_readlane(we, i);
+                uint32_t bi = __builtin_amdgcn_readlane(b, i);
+                bool oki = __builtin_amdgcn_readlane((uint32_t)ok, i) != 0;
+                bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
+                if (merge) {  // add_seed_hit, index.rs:216-229
+                    w.s = min(w.s, wsi);
+                    w.e = max(w.e, wei);
+                    w.n++;
+                } else {
+                    if (w.have && w.n >= g.min_seeds) {  // index.rs:467-469
+                        if (lane == 0) {
+                            gstore(ct + 2ull * nc, ((uint64_t)w.e << 32) | w.s);
+                            gstore(ct + 2ull * nc + 1, ((uint64_t)w.n << 32) | w.b);
+                        }
+                        nc++;
+                    }
+                    w.have = oki;
+                    w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
+                }
+            }
+        }
+        if (w.have && w.n >= g.min_seeds) {  // index.rs:481-485
+            if (lane == 0) {
+                gstore(ct + 2ull * nc, ((uint64_t)w.e << 32) | w.s);
+                gstore(ct + 2ull * nc + 1, ((uint64_t)w.n << 32) | w.b);
+            }
+            nc++;
+        }
+        if (BLK && threadIdx.x == 0) *sh_nc = nc;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    km.sync();
+    if (BLK) nc = *sh_nc;
+    // rank: sort (num_seeds descending, walk order ascending) -- the stable sort of index.rs:369
+    for (uint32_t i = tid; i < nc; i += nt) {
+        uint32_t n_i = (uint32_t)(gload(ct + 2ull * i + 1) >> 32);
+        km.st(i, ((uint64_t)(0xffffffffu - n_i) << 32) | i);
+    }
+    km.sync();
+    big_sort(km, nc);
+    for (uint32_t base = 0; base < nc; base += nt) {  // every thread runs the same trip count (barrier below)
+        uint32_t i = base + tid;
+        uint64_t taxkey = 0;
+        if (i < nc) {
+            uint32_t src = (uint32_t)km.ld(i);
+            uint64_t se = gload(ct + 2ull * src), bn = gload(ct + 2ull * src + 1);
+            a.cand[o + i] = make_uint4((uint32_t)se, (uint32_t)(se >> 32), (uint32_t)bn, (uint32_t)(bn >> 32));
+            a.cand_rs[o + i] = rs;
+            a.cand_status[o + i] = 0;
+            taxkey = ((uint64_t)ix.bins[(uint32_t)bn].tax_id << 32) | i;  // (TaxId, rank)
+        }
+        km.sync();  // all reads of this tile's rank keys are done before they are overwritten
+        if (i < nc) km.st(i, taxkey);
+    }
+    km.sync();
+    big_sort(km, nc);
+    for (uint32_t base = (BLK ? (threadIdx.x / kWave) * kWave : 0); base < nc; base += nt) {
+        uint32_t p = base + lane;
+        bool emit = false;
+        uint32_t rk = 0;
+        if (p < nc) {
+            uint64_t k0 = km.ld(p);
+            uint64_t kn = p + 1 < nc ? km.ld(p + 1) : ~0ull;
+            uint64_t kp = p > 0 ? km.ld(p - 1) : ~0ull;
+            rk = (uint32_t)k0;
+            a.cand_next[o + rk] = (kn >> 32) == (k0 >> 32) ? (uint32_t)kn : 0xffffffffu;
+            emit = (p == 0 || (kp >> 32) != (k0 >> 32)) && rk < a.maxc;
+        }
+        unsigned long long em = __ballot(emit);
+        if (em) {
+            uint32_t b2 = 0;
+            if (lane == 0) b2 = atomicAdd(a.wl_count, (uint32_t)__popcll(em));
+            b2 = __builtin_amdgcn_readfirstlane(b2);
+            if (emit) a.worklist[b2 + __popcll(em & ((1ull << lane) - 1))] = o + rk;
+        }
+    }
+    if (tid == 0) {
+        a.strand_ncand[rs] = nc;
+        if (nc) atomicAdd(a.n_cand_total, (unsigned long long)nc);
+    }
+    km.sync();  // the key array is free for the next strand
+}
+
+__global__ __launch_bounds__(256) void k_coalesce_heavy(DevIndexView ix, HeavyArgs a, const uint32_t* __restrict__ heavy_list,
+                                                        const uint32_t* __restrict__ heavy_count) {
+    __shared__ uint64_t lk[kHeavyKeys];
+    __shared__ uint32_t sh_nc;
+    const uint32_t n_heavy = *heavy_count;
+    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
+        const uint32_t rs = heavy_list[h];
+        const uint32_t nh = a.strand_off[rs + 1] - a.strand_off[rs];
+        if (nh <= kHeavyKeys) {
+            coalesce_big<true>(ix, a, rs, KeyMem<true>{lk}, &sh_nc);
+        } else {
+            if (threadIdx.x < kWave) coalesce_big<false>(ix, a, rs, KeyMem<false>{a.hit_key + a.strand_off[rs]}, nullptr);
+            __syncthreads();
+        }
+    }
+}
+
 
 __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_t* __restrict__ read_off, uint32_t r0,
                                                   uint32_t n_strands, double edit_rate, double min_seed,
@@ -426,6 +598,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
                                                   uint32_t* __restrict__ cand_status,
                                                   uint32_t* __restrict__ strand_ncand,
                                                   uint32_t* __restrict__ worklist, uint32_t* __restrict__ wl_count,
+                                                  uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
                                                   unsigned long long* __restrict__ n_cand_total) {
     __shared__ uint32_t pend_all[256 / kWave][kWave];
     uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
@@ -436,7 +609,113 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
     const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
     uint32_t pend = 0;  // work items buffered in pend_buf (wave-uniform)
     unsigned long long cand_sum = 0;
-    for (uint32_t rs = wave; rs < n_strands; rs += n_waves) {
+    for (uint32_t rs4 = wave * 4; rs4 < n_strands; rs4 += n_waves * 4) {
+      // ---- fast path: four strands at once, one per 16-lane group, when each has <= 16 seed hits ----
+      {
+        const uint32_t gl = lane & 15, gbase = lane & 48;
+        const uint32_t grs = rs4 + (lane >> 4);
+        const bool gvalid = grs < n_strands;
+        const uint32_t go = gvalid ? strand_off[grs] : 0;
+        const uint32_t gnh = gvalid ? strand_off[grs + 1] - go : 0;
+        if (!__any(gnh > 16)) {
+            uint32_t maxnh = gnh;
+            maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 16));
+            maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 32));
+            maxnh = __builtin_amdgcn_readfirstlane(maxnh);
+            if (maxnh == 0) {
+                if (gvalid && gl == 0) strand_ncand[grs] = 0;
+                continue;
+            }
+            StrandGeom gg{0, 0, 1};
+            if (gvalid && gnh) gg = strand_geom(read_off, r0 + (grs >> 1), edit_rate, min_seed, strand_nseeds[grs]);
+            uint64_t key = gl < gnh ? ((uint64_t)hit_ref[go + gl] << 32) | hit_q[go + gl] : ~0ull;
+            for (uint32_t k = 2; k <= 16; k <<= 1)  // bitonic sort inside the 16-lane group
+                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                    uint64_t other = __shfl_xor(key, j);
+                    bool up = (gl & k) == 0, lower = (gl & j) == 0;
+                    key = (lower == up) ? min(key, other) : max(key, other);
+                }
+            uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
+            uint32_t b = 0, ws = 0, we = 0;
+            bool ok = false;
+            if (gl < gnh) {
+                b = min(find_bin(ix, site), ix.n_bins - 1);
+                DevBin bin = ix.bins[b];
+                ok = candidate_window(site, q, bin, gg.L, gg.ED, &ws, &we);
+            }
+            Walk w{false, 0, 0, 0, 0};
+            uint32_t gnc = 0, ms = 0, me = 0, mb = 0, mn = 0;
+            for (uint32_t i = 0; i < maxnh; i++) {
+                const int src = (int)(gbase + i);
+                uint32_t wsi = (uint32_t)__shfl((int)ws, src), wei = (uint32_t)__shfl((int)we, src);
+                uint32_t bi = (uint32_t)__shfl((int)b, src);
+                bool oki = __shfl((int)ok, src) != 0;
+                if (i < gnh) {
+                    bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
+                    if (merge) {
+                        w.s = min(w.s, wsi);
+                        w.e = max(w.e, wei);
+                        w.n++;
+                    } else {
+                        if (w.have && w.n >= gg.min_seeds) {
+                            if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
+                            gnc++;
+                        }
+                        w.have = oki;
+                        w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
+                    }
+                }
+            }
+            if (w.have && w.n >= gg.min_seeds) {
+                if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
+                gnc++;
+            }
+            uint32_t maxnc = gnc;
+            maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 16));
+            maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 32));
+            maxnc = __builtin_amdgcn_readfirstlane(maxnc);
+            const uint32_t tax = gl < gnc ? ix.bins[mb].tax_id : 0;
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < maxnc; j++) {
+                uint32_t nj = (uint32_t)__shfl((int)mn, (int)(gbase + j));
+                if (j < gnc) rank += (nj > mn) || (nj == mn && j < gl);
+            }
+            uint32_t nxt = 0xffffffffu;
+            bool first = gl < gnc;
+            for (uint32_t j = 0; j < maxnc; j++) {
+                uint32_t tj = (uint32_t)__shfl((int)tax, (int)(gbase + j)), rj = (uint32_t)__shfl((int)rank, (int)(gbase + j));
+                if (j < gnc) {
+                    if (tj == tax && rj > rank && rj < nxt) nxt = rj;
+                    if (tj == tax && rj < rank) first = false;
+                }
+            }
+            if (gl < gnc) {
+                cand[go + rank] = make_uint4(ms, me, mb, mn);
+                cand_next[go + rank] = nxt;
+                cand_rs[go + rank] = grs;
+                cand_status[go + rank] = 0;
+            }
+            if (gvalid && gl == 0) strand_ncand[grs] = gnc;
+            if (gl == 0) cand_sum += gnc;
+            {
+                bool emit = first && rank < maxc;
+                unsigned long long em = __ballot(emit);
+                uint32_t m = __popcll(em);
+                if (pend + m > kWave) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(wl_count, pend);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (lane < pend) worklist[base + lane] = pend_buf[lane];
+                    pend = 0;
+                }
+                if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = go + rank;
+                pend += m;
+            }
+            continue;
+        }
+      }
+      // ---- general path: one strand at a time over the whole wavefront ----
+      for (uint32_t rs = rs4; rs < min(rs4 + 4, n_strands); rs++) {
         const uint32_t o = strand_off[rs];
         const uint32_t nh = __builtin_amdgcn_readfirstlane(strand_off[rs + 1] - o);
         if (nh == 0) {
@@ -518,94 +797,13 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
                 pend += m;
             }
         } else {
-            // ---- segments longer than a wavefront: sort in L2-resident scratch ----
-            uint64_t* keys = hit_key + o;
-            for (uint32_t i = lane; i < nh; i += kWave) gstore(keys + i, ((uint64_t)hit_ref[o + i] << 32) | hit_q[o + i]);
-            wave_mem_sync();
-            global_bitonic_sort(keys, nh);
-            Walk w{false, 0, 0, 0, 0};
-            uint64_t* ct = cand_tmp + 2ull * o;
-            for (uint32_t base = 0; base < nh; base += kWave) {
-                uint32_t cntv = min((uint32_t)kWave, nh - base);
-                uint32_t b = 0, ws = 0, we = 0;
-                bool ok = false;
-                if (lane < cntv) {
-                    uint64_t key = gload(keys + base + lane);
-                    uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-                    b = min(find_bin(ix, site), ix.n_bins - 1);
-                    DevBin bin = ix.bins[b];
-                    ok = candidate_window(site, q, bin, g.L, g.ED, &ws, &we);
-                }
-                for (uint32_t i = 0; i < cntv; i++) {
-                    uint32_t wsi = __builtin_amdgcn_readlane(ws, i), wei = __builtin_amdgcn_readlane(we, i);
-                    uint32_t bi = __builtin_amdgcn_readlane(b, i);
-                    bool oki = __builtin_amdgcn_readlane((uint32_t)ok, i) != 0;
-                    bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
-                    if (merge) {
-                        w.s = min(w.s, wsi);
-                        w.e = max(w.e, wei);
-                        w.n++;
-                    } else {
-                        if (w.have && w.n >= g.min_seeds) {
-                            if (lane == 0) {
-                                gstore(ct + 2ull * nc, ((uint64_t)w.e << 32) | w.s);
-                                gstore(ct + 2ull * nc + 1, ((uint64_t)w.n << 32) | w.b);
-                            }
-                            nc++;
-                        }
-                        w.have = oki;
-                        w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
-                    }
-                }
-            }
-            if (w.have && w.n >= g.min_seeds) {
-                if (lane == 0) {
-                    gstore(ct + 2ull * nc, ((uint64_t)w.e << 32) | w.s);
-                    gstore(ct + 2ull * nc + 1, ((uint64_t)w.n << 32) | w.b);
-                }
-                nc++;
-            }
-            wave_mem_sync();
-            // rank: sort (num_seeds descending, walk order ascending)
-            for (uint32_t i = lane; i < nc; i += kWave) {
-                uint32_t n_i = (uint32_t)(gload(ct + 2ull * i + 1) >> 32);
-                gstore(keys + i, ((uint64_t)(0xffffffffu - n_i) << 32) | i);
-            }
-            wave_mem_sync();
-            global_bitonic_sort(keys, nc);
-            for (uint32_t i = lane; i < nc; i += kWave) {
-                uint32_t src = (uint32_t)gload(keys + i);
-                uint64_t se = gload(ct + 2ull * src), bn = gload(ct + 2ull * src + 1);
-                cand[o + i] = make_uint4((uint32_t)se, (uint32_t)(se >> 32), (uint32_t)bn, (uint32_t)(bn >> 32));
-                cand_rs[o + i] = rs;
-                cand_status[o + i] = 0;
-                gstore(keys + i, ((uint64_t)ix.bins[(uint32_t)bn].tax_id << 32) | i);  // (TaxId, rank)
-            }
-            wave_mem_sync();
-            global_bitonic_sort(keys, nc);
-            for (uint32_t base = 0; base < nc; base += kWave) {
-                uint32_t p = base + lane;
-                bool emit = false;
-                uint32_t rk = 0;
-                if (p < nc) {
-                    uint64_t k0 = gload(keys + p);
-                    uint64_t kn = p + 1 < nc ? gload(keys + p + 1) : ~0ull;
-                    uint64_t kp = p > 0 ? gload(keys + p - 1) : ~0ull;
-                    rk = (uint32_t)k0;
-                    cand_next[o + rk] = (kn >> 32) == (k0 >> 32) ? (uint32_t)kn : 0xffffffffu;
-                    emit = (p == 0 || (kp >> 32) != (k0 >> 32)) && rk < maxc;
-                }
-                unsigned long long em = __ballot(emit);
-                if (em) {
-                    uint32_t b2 = 0;
-                    if (lane == 0) b2 = atomicAdd(wl_count, (uint32_t)__popcll(em));
-                    b2 = __builtin_amdgcn_readfirstlane(b2);
-                    if (emit) worklist[b2 + __popcll(em & ((1ull << lane) - 1))] = o + rk;
-                }
-            }
+            // ---- segments longer than a wavefront go to k_coalesce_heavy (block per strand, LDS sort) ----
+            if (lane == 0) heavy_list[atomicAdd(heavy_count, 1u)] = rs;
+            continue;
         }
         if (lane == 0) strand_ncand[rs] = nc;
-        cand_sum += nc;
+        if (lane == 0) cand_sum += nc;
+      }
     }
     if (pend) {
         uint32_t base = 0;
@@ -613,6 +811,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
         base = __builtin_amdgcn_readfirstlane(base);
         if (lane < pend) worklist[base + lane] = pend_buf[lane];
     }
+    for (int d = 32; d > 0; d >>= 1) cand_sum += __shfl_down(cand_sum, d);
     if (lane == 0 && cand_sum) atomicAdd(n_cand_total, cand_sum);
 }
 
@@ -874,6 +1073,23 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
 // the last row) with Myers' bit-vector recurrence, one lane per candidate, W 64-bit words per
 // column.  Read 'N' matches nothing (index.rs:272-279), reference 'N' matches nothing either.
 // ---------------------------------------------------------------------------------------------
+// 16 window symbols starting at text[pos] (any alignment) as four little-endian dwords; bytes past
+// the text read as 7.  Aligned dword loads + v_alignbyte.
+__device__ inline uint4 load16(const uint8_t* __restrict__ text, uint32_t n, uint32_t pos) {
+    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(text);
+    const uint32_t w0 = pos >> 2, sh = pos & 3;
+    const uint32_t lastw = (n - 1) >> 2;  // text allocations are padded to a dword multiple
+    uint32_t d[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = (w0 + k <= lastw) ? t32[w0 + k] : 0x07070707u;
+    uint4 r;
+    r.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+    r.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+    r.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+    r.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+    return r;
+}
+
 template <int W>
 __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a) {
     const uint32_t n_work = *a.wl_count;
@@ -893,52 +1109,71 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
         const uint32_t ED = (uint32_t)ceil((double)L * a.edit_rate);
         const bool thr_wrapped = 2ull * ED > (uint64_t)L;
         const uint8_t* read = a.bases + b0;
+        // match masks of the FORWARD read; the reverse strand walks the window backwards with
+        // complemented symbols instead (edit distance is invariant under reversing both strings)
         uint64_t eqA[W], eqC[W], eqG[W], eqT[W], Pv[W], Mv[W];
 #pragma unroll
         for (int k = 0; k < W; k++) {
-            eqA[k] = eqC[k] = eqG[k] = eqT[k] = 0;
-            Pv[k] = ~0ull;
-            Mv[k] = 0;
-            for (uint32_t b = 0; b < 64; b++) {
+            uint64_t mA = 0, mC = 0, mG = 0, mT = 0;
+            for (uint32_t b = 0; b < 64; b += 4) {
                 uint32_t p = k * 64 + b;
                 if (p >= L) break;
-                uint32_t code = strand_code(read, L, strand, p);
-                uint64_t bit = 1ull << b;
-                eqA[k] |= code == 0 ? bit : 0;
-                eqC[k] |= code == 1 ? bit : 0;
-                eqG[k] |= code == 2 ? bit : 0;
-                eqT[k] |= code == 3 ? bit : 0;
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    uint32_t code = p + q < L ? base_code(read[p + q]) : 7u;
+                    uint64_t bit = 1ull << (b + q);
+                    mA |= code == 0 ? bit : 0;
+                    mC |= code == 1 ? bit : 0;
+                    mG |= code == 2 ? bit : 0;
+                    mT |= code == 3 ? bit : 0;
+                }
             }
+            eqA[k] = mA; eqC[k] = mC; eqG[k] = mG; eqT[k] = mT;
+            Pv[k] = ~0ull;
+            Mv[k] = 0;
         }
         const uint32_t Wn = c.y - c.x;
-        const int last_blk = (int)((L - 1) / 64);
-        const uint32_t last_bit = (L - 1) & 63;
+        const uint32_t last_blk = (L - 1) / 64, last_bit = (L - 1) & 63;
         int score = (int)L, best = (int)L;  // D[L][0] = L
-        for (uint32_t j = 0; j < Wn; j++) {
-            const uint32_t pos = c.x + j;
-            const uint32_t tc = pos < ix.n ? ix.text[pos] : 7u;
-            int hin = 0;  // first row is all zeros: no horizontal delta enters block 0
-#pragma unroll
-            for (int k = 0; k < W; k++) {
-                if (k > last_blk) break;
-                uint64_t Eq = tc == 0 ? eqA[k] : tc == 1 ? eqC[k] : tc == 2 ? eqG[k] : tc == 3 ? eqT[k] : 0ull;
-                const uint64_t pv = Pv[k], mv = Mv[k];
-                const uint64_t Xv = Eq | mv;
-                if (hin < 0) Eq |= 1ull;
-                const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-                uint64_t Ph = mv | ~(Xh | pv);
-                uint64_t Mh = pv & Xh;
-                if (k == last_blk) score += (int)((Ph >> last_bit) & 1) - (int)((Mh >> last_bit) & 1);
-                const int hout = (int)(Ph >> 63) - (int)(Mh >> 63);
-                Ph <<= 1;
-                Mh <<= 1;
-                if (hin < 0) Mh |= 1ull;
-                else if (hin > 0) Ph |= 1ull;
-                Pv[k] = Mh | ~(Xv | Ph);
-                Mv[k] = Ph & Xv;
-                hin = hout;
+        uint4 nxt4 = Wn ? load16(ix.text, ix.n, strand ? (c.y >= 16 ? c.y - 16 : 0) : c.x) : make_uint4(0, 0, 0, 0);
+        for (uint32_t j0 = 0; j0 < Wn; j0 += 16) {
+            const uint4 cur = nxt4;
+            const uint32_t jn = j0 + 16;
+            if (jn < Wn) {  // prefetch the next 16 columns
+                uint32_t pos = strand ? (c.y >= jn + 16 ? c.y - jn - 16 : 0) : c.x + jn;
+                nxt4 = load16(ix.text, ix.n, pos);
             }
-            best = min(best, score);
+            const uint32_t lim = min(16u, Wn - j0);
+            // for the reverse walk the chunk holds text[c.y-j0-16 .. c.y-j0): consume from its top; when the
+            // window start clamps at 0 the chunk is aligned to text position 0 instead
+            const uint32_t rev_base = strand ? (c.y >= j0 + 16 ? 0u : (j0 + 16 - c.y)) : 0u;
+            for (uint32_t jj = 0; jj < lim; jj++) {
+                uint32_t bi = strand ? (15u - jj - rev_base) : jj;
+                uint32_t word = bi < 4 ? cur.x : bi < 8 ? cur.y : bi < 12 ? cur.z : cur.w;
+                uint32_t tc = (word >> ((bi & 3) * 8)) & 0xffu;
+                if (strand) tc = tc < 4 ? 3 - tc : tc;  // complement
+                uint64_t hp = 0, hm = 0;  // horizontal delta entering block 0 is 0 (first row all zeros)
+#pragma unroll
+                for (int k = 0; k < W; k++) {
+                    uint64_t Eq = tc == 0 ? eqA[k] : (tc == 1 ? eqC[k] : (tc == 2 ? eqG[k] : (tc == 3 ? eqT[k] : 0ull)));
+                    const uint64_t pv = Pv[k], mv = Mv[k];
+                    const uint64_t Xv = Eq | mv;
+                    Eq |= hm;
+                    const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                    uint64_t Ph = mv | ~(Xh | pv);
+                    uint64_t Mh = pv & Xh;
+                    int d = (int)((Ph >> last_bit) & 1) - (int)((Mh >> last_bit) & 1);
+                    score += ((uint32_t)k == last_blk) ? d : 0;
+                    const uint64_t op = Ph >> 63, om = Mh >> 63;
+                    Ph = (Ph << 1) | hp;
+                    Mh = (Mh << 1) | hm;
+                    Pv[k] = Mh | ~(Xv | Ph);
+                    Mv[k] = Ph & Xv;
+                    hp = op;
+                    hm = om;
+                }
+                best = min(best, score);
+            }
         }
         verified++;
         wbytes += Wn;
@@ -1064,11 +1299,35 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                      double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
                      const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
                      uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_rs, uint32_t* cand_status,
-                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, unsigned long long* n_cand_total) {
-    uint32_t blocks = std::min<uint32_t>(cdiv(n_strands, 4), 256 * 8);
+                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, uint32_t* heavy_list,
+                     uint32_t* heavy_count, unsigned long long* n_cand_total) {
+    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n_strands, 16), 256 * 8));  // 4 strands per wavefront pass
     hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, read_off, r0, n_strands, edit_rate, min_seed,
                        max_candidates, strand_off, strand_nseeds, hit_ref, hit_q, hit_key, cand_tmp, cand, cand_next, cand_rs,
-                       cand_status, strand_ncand, worklist, wl_count, n_cand_total);
+                       cand_status, strand_ncand, worklist, wl_count, heavy_list, heavy_count, n_cand_total);
+    HeavyArgs a;
+    a.read_off = read_off;
+    a.r0 = r0;
+    a.edit_rate = edit_rate;
+    a.min_seed = min_seed;
+    a.maxc = max_candidates < 0 ? 0xffffffffu : (max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)max_candidates);
+    a.strand_off = strand_off;
+    a.strand_nseeds = strand_nseeds;
+    a.hit_ref = hit_ref;
+    a.hit_q = hit_q;
+    a.hit_key = hit_key;
+    a.cand_tmp = cand_tmp;
+    a.cand = cand;
+    a.cand_next = cand_next;
+    a.cand_rs = cand_rs;
+    a.cand_status = cand_status;
+    a.strand_ncand = strand_ncand;
+    a.worklist = worklist;
+    a.wl_count = wl_count;
+    a.n_cand_total = n_cand_total;
+    // persistent workgroups over the (device-side) list of heavy strands; usually a few thousand at most
+    hipLaunchKernelGGL(k_coalesce_heavy, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 64, 1), 1024)), dim3(256), 0, s, ix, a,
+                       heavy_list, heavy_count);
 }
 
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {

@@ -56,7 +56,8 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                      double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
                      const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
                      uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_rs, uint32_t* cand_status,
-                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, unsigned long long* n_cand_total);
+                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, uint32_t* heavy_list,
+                     uint32_t* heavy_count, unsigned long long* n_cand_total);
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
 // edit-first order (reads up to 253 bases): Myers bit-vector edit distance, lane per candidate
 void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
