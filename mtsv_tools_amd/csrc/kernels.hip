@@ -978,6 +978,50 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                     ring[col & (kRing - 1)] = pos < ix.n ? ix.text[pos] : (uint8_t)7;
                 }
             }
+            // Exact early rejection, every 32 steps.  The lanes' current cells form a staircase frontier
+            // (row i of lane g is at column t-1-g; a path can leave the swept region one column left of
+            // it, hence the +-1 slack).  Any alignment touching unswept cells scores at most
+            //   max_i H_i + 2 + min(rows left, columns left)   or   columns left (if it starts there),
+            // and needs at least  min_i D_i - 2 + max(0, rows left - columns left)  edits.  If neither
+            // the swept part nor that bound can reach the SW threshold, or both exceed the edit
+            // tolerance, the candidate fails index.rs:406 or :410 whatever the remaining cells hold.
+            if (!WORD && (t & 31) == 0 && t >= 32 && t < Wn) {
+                const int jl = (int)t - 1 - (int)gl;                       // last column this lane has swept (-1: none)
+                const int jc = min(jl, (int)Wn - 1);
+                const int cols_left = (int)Wn - 1 - jc;
+                const int L_ = (int)(thr + 2 * ED);
+                const int pad = (int)(kGroup * R) - L_;
+                int sw_ub = 0, ed_lb = 0x7fff;
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int p = (int)(gl * R + r) - pad;
+                    int rows_left = L_ - 1 - p;
+                    int hsw = h[r].x, hd = -(int)h[r].y;
+                    int s1 = hsw + 2 + min(rows_left, cols_left);
+                    int e1 = hd - 2 + max(0, rows_left - cols_left);
+                    sw_ub = max(sw_ub, p >= 0 ? s1 : 0);
+                    ed_lb = min(ed_lb, p >= 0 ? e1 : 0x7fff);
+                }
+                if (gl == 0) ed_lb = min(ed_lb, max(0, L_ - cols_left));  // paths still in the free first row
+                sw_ub = max(sw_ub, (int)best.x);
+                if (gl == kGroup - 1) ed_lb = min(ed_lb, -(int)last.y);     // best of the last row so far
+#pragma unroll
+                for (int d = 1; d < (int)kGroup; d <<= 1) {
+                    sw_ub = max(sw_ub, __shfl_xor(sw_ub, d));
+                    ed_lb = min(ed_lb, __shfl_xor(ed_lb, d));
+                }
+                sw_ub = max(sw_ub, (int)Wn - (int)t + (int)kGroup);          // alignments that start in unswept columns
+                if (thr_wrapped || sw_ub < (int)thr || ed_lb > (int)ED) {
+                    if (gl == 0) {
+                        a.cand_status[g] = 1;
+                        const uint32_t nxt = a.cand_next[g];
+                        if (nxt != 0xffffffffu && nxt < maxc) a.worklist_next[atomicAdd(a.wl_next_count, 1u)] = o + nxt;
+                    }
+                    phase = PH_FETCH;
+                }
+            }
+        }
+        if (phase == PH_SWEEP) {
             const uint32_t c = c_next;
             const int j = (int)t - (int)gl;
             c_next = ring[(uint32_t)(j + 1) & (kRing - 1)];
