@@ -1,0 +1,239 @@
+// mtsv-collapse -- merge the result files of several mtsv-binner runs (one per index chunk), as
+// src/collapse.rs:543-654 / src/bin/mtsv-collapse.rs:14-89 do: group lines by read id, keep the
+// smallest edit per TaxId (mode taxid) or per (TaxId, GI) with the smallest offset as tie-break
+// (mode taxid-gi), write one line per read id in ascending read-id order, optional per-TaxId
+// report (collapse.rs:717-753).  Host-side text processing: SURVEY 8(f) rank 2, needed to score
+// BASELINE config 5 (one index chunk per GPU, reads broadcast).  Inputs are sorted in memory.
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+namespace {
+
+[[noreturn]] void die(const std::string& m) {
+    fprintf(stderr, "thread 'main' panicked: Problem collapsing files: %s\n", m.c_str());
+    exit(101);
+}
+
+struct Hit {
+    uint32_t tax, gi;
+    uint64_t off;
+    uint32_t edit;
+    bool has_gi, has_off;
+};
+
+bool parse_u64(const std::string& s, uint64_t max, uint64_t* out) {
+    if (s.empty()) return false;
+    uint64_t v = 0;
+    for (char c : s) {
+        if (c < '0' || c > '9') return false;
+        v = v * 10 + (uint64_t)(c - '0');
+        if (v > max) return false;
+    }
+    *out = v;
+    return true;
+}
+
+// parse_hit_token, collapse.rs:198-255: tax[-gi[-offset]]=edit
+Hit parse_token(const std::string& tok) {
+    size_t eq = tok.find('=');
+    if (eq == std::string::npos || tok.find('=', eq + 1) != std::string::npos) die("InvalidHeader(" + tok + ")");
+    std::string left = tok.substr(0, eq);
+    uint64_t v;
+    Hit h{0, 0, 0, 0, false, false};
+    if (!parse_u64(tok.substr(eq + 1), 0xffffffffull, &v)) die("InvalidInteger(" + tok.substr(eq + 1) + ")");
+    h.edit = (uint32_t)v;
+    std::vector<std::string> parts;
+    size_t p = 0;
+    for (;;) {
+        size_t d = left.find('-', p);
+        parts.push_back(left.substr(p, d == std::string::npos ? std::string::npos : d - p));
+        if (d == std::string::npos) break;
+        p = d + 1;
+    }
+    if (parts.size() > 3) die("InvalidHeader(" + tok + ")");
+    if (!parse_u64(parts[0], 0xffffffffull, &v)) die("InvalidInteger(" + parts[0] + ")");
+    h.tax = (uint32_t)v;
+    if (parts.size() > 1) {
+        if (!parse_u64(parts[1], 0xffffffffull, &v)) die("InvalidInteger(" + parts[1] + ")");
+        h.gi = (uint32_t)v;
+        h.has_gi = true;
+    }
+    if (parts.size() > 2) {
+        if (!parse_u64(parts[2], ~0ull / 10, &v)) die("InvalidInteger(" + parts[2] + ")");
+        h.off = v;
+        h.has_off = true;
+    }
+    return h;
+}
+
+struct Stats {
+    uint64_t only_hit = 0, only_best = 0, tied_best = 0, not_best = 0;
+};
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    std::string out_path, mode = "taxid", report;
+    std::vector<std::string> files;
+    for (int i = 1; i < argc; i++) {
+        std::string k = argv[i];
+        auto val = [&]() -> std::string {
+            if (i + 1 >= argc) {
+                fprintf(stderr, "error: The argument '%s' requires a value but none was supplied\n", k.c_str());
+                exit(1);
+            }
+            return argv[++i];
+        };
+        if (k == "-o" || k == "--output") out_path = val();
+        else if (k == "--mode") mode = val();
+        else if (k == "-t" || k == "--threads") (void)val();
+        else if (k == "--report") report = val();
+        else if (k == "-v") {
+        } else if (k == "-h" || k == "--help") {
+            printf("mtsv-collapse -o <OUTPUT> [--mode taxid|taxid-gi] [--report <TSV>] [-t N] <FILES>...\n");
+            return 0;
+        } else if (!k.empty() && k[0] == '-') {
+            fprintf(stderr, "error: Found argument '%s' which wasn't expected\n", k.c_str());
+            return 1;
+        } else
+            files.push_back(k);
+    }
+    if (out_path.empty() || files.empty() || (mode != "taxid" && mode != "taxid-gi")) {
+        fprintf(stderr, "error: required: -o <OUTPUT> <FILES>..., --mode taxid|taxid-gi\n");
+        return 1;
+    }
+    const bool by_gi = mode == "taxid-gi";
+
+    // (read id, file index, hits text); sorted by (read id, file index) like the heap of collapse.rs:553-566
+    struct Line {
+        std::string id, hits;
+        size_t file;
+    };
+    std::vector<Line> lines;
+    for (size_t f = 0; f < files.size(); f++) {
+        std::ifstream in(files[f], std::ios::binary);
+        if (!in) die("cannot open " + files[f]);
+        std::string l;
+        while (std::getline(in, l)) {
+            while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back();
+            if (l.find_first_not_of(" \t") == std::string::npos) continue;
+            size_t c = l.rfind(':');  // rsplitn(2, ':'), collapse.rs:180-191
+            if (c == std::string::npos || c == 0) die("InvalidHeader(" + l + ")");
+            lines.push_back(Line{l.substr(0, c), l.substr(c + 1), f});
+        }
+    }
+    std::stable_sort(lines.begin(), lines.end(), [](const Line& a, const Line& b) {
+        if (a.id != b.id) return a.id < b.id;
+        return a.file < b.file;
+    });
+
+    FILE* out = fopen(out_path.c_str(), "wb");
+    if (!out) {
+        fprintf(stderr, "thread 'main' panicked: Unable to create output file.\n");
+        return 101;
+    }
+    std::map<uint32_t, Stats> stats;
+    uint64_t total_reads = 0;
+    int offset_format = -1;  // unknown / 0 / 1
+    size_t i = 0;
+    std::string text;
+    char num[96];
+    while (i < lines.size()) {
+        size_t j = i;
+        std::map<uint32_t, uint32_t> tax_hits;                                      // taxid -> min edit
+        std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint64_t>> gi_hits;  // (taxid, gi) -> (edit, offset)
+        for (; j < lines.size() && lines[j].id == lines[i].id; j++) {
+            const std::string& hs = lines[j].hits;
+            size_t p = 0;
+            while (!hs.empty()) {
+                size_t c = hs.find(',', p);
+                Hit h = parse_token(hs.substr(p, c == std::string::npos ? std::string::npos : c - p));
+                if (!by_gi) {
+                    auto it = tax_hits.find(h.tax);
+                    if (it == tax_hits.end()) tax_hits[h.tax] = h.edit;
+                    else if (h.edit < it->second) it->second = h.edit;
+                } else {
+                    if (!h.has_gi) die("InvalidHeader(Missing GI for taxid-gi collapse)");
+                    if (offset_format >= 0 && (offset_format == 1) != h.has_off) die("InvalidHeader(Mixed offset formats in collapse input)");
+                    offset_format = h.has_off ? 1 : 0;
+                    auto key = std::make_pair(h.tax, h.gi);
+                    auto it = gi_hits.find(key);
+                    if (it == gi_hits.end()) gi_hits[key] = {h.edit, h.off};
+                    else if (h.edit < it->second.first || (h.edit == it->second.first && h.off < it->second.second)) it->second = {h.edit, h.off};
+                }
+                if (c == std::string::npos) break;
+                p = c + 1;
+            }
+        }
+        // per-taxid summary + stats (collapse.rs:94-147)
+        std::map<uint32_t, uint32_t> summary;
+        if (!by_gi) summary = tax_hits;
+        else
+            for (auto& kv : gi_hits) {
+                auto it = summary.find(kv.first.first);
+                if (it == summary.end()) summary[kv.first.first] = kv.second.first;
+                else if (kv.second.first < it->second) it->second = kv.second.first;
+            }
+        if (!summary.empty()) {
+            uint32_t mn = 0xffffffffu;
+            for (auto& kv : summary) mn = std::min(mn, kv.second);
+            size_t best = 0;
+            for (auto& kv : summary) best += kv.second == mn;
+            total_reads++;
+            for (auto& kv : summary) {
+                Stats& s = stats[kv.first];
+                if (summary.size() == 1) s.only_hit++;
+                else if (kv.second == mn) (best == 1 ? s.only_best : s.tied_best)++;
+                else s.not_best++;
+            }
+        }
+        // write (collapse.rs:269-337)
+        text.clear();
+        bool any = false;
+        if (!by_gi) {
+            for (auto& kv : tax_hits) {
+                snprintf(num, sizeof num, "%s%u=%u", any ? "," : "", kv.first, kv.second);
+                text += num;
+                any = true;
+            }
+        } else {
+            for (auto& kv : gi_hits) {
+                if (offset_format == 1)
+                    snprintf(num, sizeof num, "%s%u-%u-%llu=%u", any ? "," : "", kv.first.first, kv.first.second,
+                             (unsigned long long)kv.second.second, kv.second.first);
+                else
+                    snprintf(num, sizeof num, "%s%u-%u=%u", any ? "," : "", kv.first.first, kv.first.second, kv.second.first);
+                text += num;
+                any = true;
+            }
+        }
+        if (any) fprintf(out, "%s:%s\n", lines[i].id.c_str(), text.c_str());
+        i = j;
+    }
+    if (fclose(out) != 0) die("write error");
+    if (!report.empty()) {
+        FILE* r = fopen(report.c_str(), "wb");
+        if (!r) {
+            fprintf(stderr, "thread 'main' panicked: Unable to write taxa report\n");
+            return 101;
+        }
+        fprintf(r, "taxid\tonly_hit\tonly_hit_pct\tonly_best\tonly_best_pct\ttied_best\ttied_best_pct\tnot_best\tnot_best_pct\ttotal_reads\ttotal_pct\n");
+        double denom = (double)std::max<uint64_t>(total_reads, 1);
+        for (auto& kv : stats) {
+            const Stats& s = kv.second;
+            uint64_t tot = s.only_hit + s.only_best + s.tied_best + s.not_best;
+            fprintf(r, "%u\t%llu\t%.2f\t%llu\t%.2f\t%llu\t%.2f\t%llu\t%.2f\t%llu\t%.2f\n", kv.first, (unsigned long long)s.only_hit,
+                    s.only_hit / denom * 100.0, (unsigned long long)s.only_best, s.only_best / denom * 100.0,
+                    (unsigned long long)s.tied_best, s.tied_best / denom * 100.0, (unsigned long long)s.not_best,
+                    s.not_best / denom * 100.0, (unsigned long long)tot, tot / denom * 100.0);
+        }
+        fclose(r);
+    }
+    return 0;
+}
