@@ -1022,6 +1022,8 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
             }
         }
         if (phase == PH_SWEEP) {
+#pragma unroll
+          for (int rep = 0; rep < 2; rep++) {  // two columns per trip of the phase loop
             const uint32_t c = c_next;
             const int j = (int)t - (int)gl;
             c_next = ring[(uint32_t)(j + 1) & (kRing - 1)];
@@ -1032,9 +1034,12 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
             if (j >= 0 && j < (int)Wn) {
                 const pk16 mvc = c == kCodeN ? pk(1, -1) : pk(1, 0);  // N/N: +1 in SW, never a match in edit distance
                 pk16 diag = up_prev, up = in;
+                bool eq[R];
+#pragma unroll
+                for (int r = 0; r < R; r++) eq[r] = qc[r] == c;  // all compares first: no VCC hazard stalls
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    pk16 sv = qc[r] == c ? mvc : miss;
+                    pk16 sv = eq[r] ? mvc : miss;
                     pk16 x = diag + sv;
                     pk16 y = pk_max(up, h[r]) - one;
                     pk16 v = pk_max(pk_max(x, y), clampRow[r]);
@@ -1063,6 +1068,8 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                 }
             }
             t++;
+            if (t >= steps) break;
+          }
             if (t >= steps) {
                 int sw = best.x;
                 sw = max(sw, __shfl_xor(sw, 1));
