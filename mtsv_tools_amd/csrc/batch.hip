@@ -34,7 +34,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     HIP_CHECK(hipSetDevice(di->device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     const uint64_t ns = 2 * max_reads;
-    dev_alloc(&d_bases, max_bases + 16, &bytes);
+    dev_alloc(&d_bases, max_bases + 64, &bytes);  // k_search reads up to 36 bytes past a seed start with dword loads
     dev_alloc(&d_read_off, max_reads + 1, &bytes);
     dev_alloc(&d_strand_hits, ns + 1, &bytes);
     dev_alloc(&d_strand_nseeds, ns, &bytes);

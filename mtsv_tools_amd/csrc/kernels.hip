@@ -40,6 +40,19 @@ __device__ inline uint32_t n_seeds_of(uint32_t L, uint32_t K, uint32_t G) {
 // ---------------------------------------------------------------------------------------------
 // K1: backward search, one lane per seed slot
 // ---------------------------------------------------------------------------------------------
+// symbol code of an ASCII byte without a table: A/a C/c G/g T/t -> 0..3, anything else -> N (4)
+__device__ inline uint32_t fast_code(uint32_t ch) {
+    uint32_t uc = ch & 0xDFu;
+    uint32_t x = (uc >> 1) & 3u;
+    uint32_t c = x ^ (x >> 1);  // A0 C1 G2 T3
+    bool acgt = uc == 'A' || uc == 'C' || uc == 'G' || uc == 'T';
+    return acgt ? c : kCodeN;
+}
+
+// Seeds of up to 32 symbols are fetched with aligned dword loads (the read buffer is padded) and
+// packed as 3-bit codes in strand order, so the search loop itself issues only rank-block loads.
+constexpr uint32_t kMaxPackedSeed = 32;
+
 __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* __restrict__ bases,
                                                 const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t n_reads,
                                                 uint32_t max_ns, uint32_t K, uint32_t G,
@@ -57,6 +70,37 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
     if (j < ns) {
         const uint8_t* read = bases + b0;
         uint32_t off = j * G;
+        // packed codes: symbol i of the seed (strand order) at bits [3i, 3i+3) of c_lo (i < 21) / c_hi
+        uint64_t c_lo = 0, c_hi = 0;
+        const bool packed = K <= kMaxPackedSeed;
+        if (packed) {
+            // forward strand: bytes [off, off+K); reverse strand: bytes [L-off-K, L-off) reversed + complemented
+            const uint32_t s0 = b0 + (strand ? L - off - K : off);
+            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
+            const uint32_t w0 = s0 >> 2, sh = s0 & 3;
+            uint32_t d[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) d[k] = b32[w0 + k];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t bi = k * 4 + q;  // byte index inside the fetched span
+                    uint32_t code = fast_code((w >> (8 * q)) & 0xffu);
+                    if (strand) code = comp_code(code);
+                    const uint32_t pos = strand ? (K - 1 - bi) : bi;  // strand-order position of this byte
+                    if (bi < K) {
+                        if (pos < 21) c_lo |= (uint64_t)code << (3 * pos);
+                        else c_hi |= (uint64_t)code << (3 * (pos - 21));
+                    }
+                }
+            }
+        }
+        auto sym = [&](uint32_t i) -> uint32_t {
+            if (packed) return (uint32_t)((i < 21 ? c_lo >> (3 * i) : c_hi >> (3 * (i - 21))) & 7u);
+            return strand_code(read, L, strand, off + i);
+        };
         lo = 0;
         hi = ix.n;
         int i = (int)K - 1;
@@ -65,7 +109,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
             uint32_t idx = 0;
             bool acgt = true;
             for (uint32_t t = 0; t < ix.kmer_k; t++) {
-                uint32_t a = strand_code(read, L, strand, off + K - ix.kmer_k + t);
+                uint32_t a = sym(K - ix.kmer_k + t);
                 acgt &= a < 4;
                 idx = (idx << 2) | (a & 3);
             }
@@ -77,7 +121,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
             }
         }
         for (; i >= 0 && lo < hi; i--) {
-            uint32_t a = strand_code(read, L, strand, off + (uint32_t)i);
+            uint32_t a = sym((uint32_t)i);
             uint32_t bl = lo >> kBlockShift, bh = hi >> kBlockShift;
             LoadedBlock B0 = load_block(ix.blocks, bl);
             uint32_t nlo = less_of(ix, a) + block_rank(B0, a, bl, lo & (kBlockRows - 1), ix.sentinel_row);
