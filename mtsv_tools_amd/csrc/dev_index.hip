@@ -31,6 +31,7 @@ DeviceIndex::~DeviceIndex() {
     (void)hipFree(d_text);
     (void)hipFree(d_bin_end);
     (void)hipFree(d_bins);
+    (void)hipFree(d_bin_lut);
     (void)hipFree(d_kmer);
 }
 
@@ -216,6 +217,19 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
         bin_end[i] = (uint32_t)hx.bins[i].end;
     }
 
+    // coarse bin lookup: bucket k covers text positions [k << shift, (k+1) << shift)
+    uint32_t lut_shift = 0;
+    while (((uint64_t)n >> lut_shift) > 65536) lut_shift++;
+    std::vector<uint32_t> bin_lut(((uint64_t)n >> lut_shift) + 2);
+    {
+        uint32_t b = 0;
+        for (size_t k = 0; k < bin_lut.size(); k++) {
+            uint64_t p = (uint64_t)k << lut_shift;
+            while (b + 1 < bins.size() && bin_end[b] <= p) b++;
+            bin_lut[k] = b;
+        }
+    }
+
     auto di = std::make_unique<DeviceIndex>();
     di->device = device;
     di->flags = flags;
@@ -229,6 +243,7 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
     up(&di->d_text, codes.data(), codes.size());
     up(&di->d_bin_end, bin_end.data(), bin_end.size() * 4);
     up(&di->d_bins, bins.data(), bins.size() * sizeof(DevBin));
+    up(&di->d_bin_lut, bin_lut.data(), bin_lut.size() * 4);
 
     DevIndexView& v = di->view;
     v.blocks = di->d_blocks;
@@ -251,6 +266,8 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
     v.bin_end = di->d_bin_end;
     v.bins = di->d_bins;
     v.n_bins = (uint32_t)bins.size();
+    v.bin_lut = di->d_bin_lut;
+    v.bin_lut_shift = lut_shift;
     v.kmer_tab = nullptr;
     v.kmer_k = 0;
 

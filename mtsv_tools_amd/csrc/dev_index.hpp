@@ -25,6 +25,7 @@ struct DeviceIndex {
     uint8_t* d_text = nullptr;
     uint32_t* d_bin_end = nullptr;
     DevBin* d_bins = nullptr;
+    uint32_t* d_bin_lut = nullptr;
     uint2* d_kmer = nullptr;
     DevIndexView view{};
     uint64_t bytes = 0;

@@ -50,6 +50,8 @@ struct DevIndexView {
     const uint32_t* bin_end;    // bins[i].end, ascending (binary-search key)
     const DevBin* bins;
     uint32_t n_bins;
+    const uint32_t* bin_lut;    // bin_lut[p >> bin_lut_shift] = first bin whose end > (p >> shift) << shift
+    uint32_t bin_lut_shift;
     const uint2* kmer_tab;      // [4^kmer_k] SA interval (lo, hi) of every ACGT k-mer, or nullptr
     uint32_t kmer_k;
 };

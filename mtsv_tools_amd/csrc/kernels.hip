@@ -367,9 +367,11 @@ __device__ inline uint64_t wave_bitonic_sort(uint64_t key) {
     return key;
 }
 
-// first bin whose end > site (the forward-only cursor of index.rs:455-458 on sorted hits)
+// first bin whose end > site (the forward-only cursor of index.rs:455-458 on sorted hits): a coarse
+// table gives the first bin that can hold the site's bucket, then a short forward scan
 __device__ inline uint32_t find_bin(const DevIndexView& ix, uint32_t site) {
-    uint32_t lo = 0, hi = ix.n_bins;
+    const uint32_t k = site >> ix.bin_lut_shift;
+    uint32_t lo = ix.bin_lut[k], hi = ix.bin_lut[k + 1];  // the answer lies in [lo, hi]; usually lo == hi
     while (lo < hi) {
         uint32_t mid = (lo + hi) >> 1;
         if (ix.bin_end[mid] <= site)
