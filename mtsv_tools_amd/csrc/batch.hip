@@ -56,7 +56,6 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_cand_rs, hit_cap, &bytes);
     dev_alloc(&d_cand_status, hit_cap, &bytes);
     dev_alloc(&d_worklist, hit_cap, &bytes);
-    dev_alloc(&d_worklist2, hit_cap, &bytes);
     dev_alloc(&d_hits, hits_cap, &bytes);
     HIP_CHECK(hipHostMalloc((void**)&h_counters, 8 * sizeof(uint64_t)));
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
@@ -70,7 +69,7 @@ Batch::~Batch() {
                     (void*)d_strand_nseeds, (void*)d_strand_off, (void*)d_strand_ncand, (void*)d_worklist,
                     (void*)d_strand_nout, (void*)d_out_off, (void*)d_tile_sums, (void*)d_counters, (void*)d_hit_row,
                     (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand, (void*)d_out,
-                    (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_worklist2, (void*)d_heavy_list})
+                    (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_heavy_list})
         (void)hipFree(p);
     (void)hipHostFree(h_counters);
     for (auto& e : ev) (void)hipEventDestroy(e);
@@ -192,35 +191,15 @@ void Batch::run(const mtsv_params& p) {
             a.out = d_out;
             a.n_verified = (unsigned long long*)(d_counters + 4);
             a.window_bytes = (unsigned long long*)(d_counters + 5);
-            uint32_t* cnt_a = (uint32_t*)(d_counters + 1);      // round 0 list
-            uint32_t* cnt_b = (uint32_t*)(d_counters + 7);      // next list
-            uint32_t* cnt_c = (uint32_t*)(d_counters + 7) + 1;  // list after that
-            uint32_t *cur = d_worklist, *nxt = d_worklist2, *cur_cnt = cnt_a, *nxt_cnt = cnt_b;
-            uint64_t upper = total_hits;  // candidates <= seed hits
-            for (uint32_t round = 0;; round++) {
-                a.worklist = cur;
-                a.wl_count = cur_cnt;
-                a.worklist_next = nxt;
-                a.wl_next_count = nxt_cnt;
-                if (verify_mode == 1 && max_len <= 253)
-                    launch_edit_myers(stream, v, a, upper, max_len);
-                else
-                    launch_evaluate(stream, v, a, upper, max_len);
-                HIP_CHECK(hipMemcpyAsync(h_counters, nxt_cnt, 4, hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipStreamSynchronize(stream));
-                const uint32_t n_next = *(const uint32_t*)h_counters;
-                stats.n_rounds = round + 1;
-                if (n_next == 0) break;
-                upper = n_next;
-                // rotate: next becomes current; the spare count slot is cleared for the round after
-                uint32_t* spare_cnt = (nxt_cnt == cnt_b) ? cnt_c : cnt_b;
-                HIP_CHECK(hipMemsetAsync(spare_cnt, 0, 4, stream));
-                uint32_t* spare_list = (nxt == d_worklist2) ? d_worklist : d_worklist2;
-                cur = nxt;
-                cur_cnt = nxt_cnt;
-                nxt = spare_list;
-                nxt_cnt = spare_cnt;
-            }
+            // one launch: a group whose candidate fails walks on to the next candidate of the same TaxId
+            a.worklist = d_worklist;
+            a.wl_count = (const uint32_t*)(d_counters + 1);
+            a.wl_cursor = (uint32_t*)(d_counters + 7);
+            if (verify_mode == 1 && max_len <= 253)
+                launch_edit_myers(stream, v, a, total_hits, max_len);
+            else
+                launch_evaluate(stream, v, a, total_hits, max_len);
+            stats.n_rounds = 1;
             launch_resolve(stream, nstr, p.max_candidates, p.max_assignments, d_strand_off, d_strand_ncand, d_cand_status,
                            d_out, d_strand_nout);
         }

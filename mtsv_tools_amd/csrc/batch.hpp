@@ -26,7 +26,7 @@ struct Batch {
     uint32_t *d_hit_row = nullptr, *d_hit_ref = nullptr, *d_hit_q = nullptr;
     uint64_t *d_hit_key = nullptr, *d_cand_tmp = nullptr;
     uint4 *d_cand = nullptr, *d_out = nullptr;
-    uint32_t *d_cand_next = nullptr, *d_cand_rs = nullptr, *d_cand_status = nullptr, *d_worklist2 = nullptr, *d_heavy_list = nullptr;
+    uint32_t *d_cand_next = nullptr, *d_cand_rs = nullptr, *d_cand_status = nullptr, *d_heavy_list = nullptr;
     DevHit* d_hits = nullptr;
     uint64_t* h_counters = nullptr;  // pinned
     hipEvent_t ev[10];

@@ -897,10 +897,12 @@ __device__ inline int row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v,
 
 __device__ inline uint32_t group_ballot(bool p, uint32_t group) { return (uint32_t)(__ballot(p) >> (group * kGroup)) & 0xffffu; }
 
-enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2 };
+enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2, PH_CHAIN = 3 };
 
-// One work item = one candidate (index into cand[]).  Items of a round are independent; a failed
-// candidate pushes the next candidate of the same TaxID (rank order) onto the next round's list.
+// One work item = the first candidate of a TaxId of a strand (index into cand[]).  When it fails, the
+// group moves on to the next candidate of that TaxId in rank order (same read rows, new window), which
+// is exactly when the reference's loop would verify it (index.rs:393).  Items are claimed four at a
+// time from an atomic cursor, so chains of failing candidates do not unbalance the groups.
 // WORD: reads of 254+ bases can push the byte kernel of ssw.c to its overflow value 255 (score >= 254,
 // ssw.c:271,302), after which ssw_align reruns sw_sse2_word (ssw.c:789-792).  With gap open == gap
 // extend that kernel's lazy-F loop (ssw.c:452-463) always leaves after its first cell, so a vertical
@@ -908,21 +910,19 @@ enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2 };
 // and E never sees the lazy correction.  Row-wise that is: hb = max(0, diag+s, left_pre-1);
 // h = max(hb, up_pre-1); pre = boundary row ? hb : h -- computed here next to the exact score.
 template <int R, bool WORD>
-__global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
+__global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevIndexView ix, EvalArgs a) {
     __shared__ uint8_t ring_all[256 / kGroup][kRing];
     const uint32_t lane = lane_id();
     const uint32_t gl = lane & (kGroup - 1);  // lane inside the group
     uint8_t* ring = ring_all[threadIdx.x / kGroup];
-    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) / kGroup;
-    const uint32_t n_groups = gridDim.x * blockDim.x / kGroup;
     const uint32_t n_work = *a.wl_count;
     const pk16 one = pk(1, 1), miss = pk(-1, -1);
     const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
                                                : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
 
     uint32_t phase = PH_FETCH;
-    uint32_t w = gid;
-    uint32_t g = 0, o = 0, ED = 0, thr = 0;
+    uint32_t loc = 0, loc_end = 0;  // this group's slice of the worklist, refilled 4 items at a time
+    uint32_t g = 0, o = 0, ED = 0, thr = 0, L = 0;
     bool thr_wrapped = false;
     uint32_t qc[R];
     pk16 clampRow[R];
@@ -942,27 +942,55 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
     }
 
     for (;;) {
-        if (phase == PH_FETCH) {
-            if (w < n_work) {
-                g = a.worklist[w];
-                w += n_groups;
+        if (phase == PH_FETCH || phase == PH_CHAIN) {
+            bool have = true;
+            if (phase == PH_FETCH) {
+                if (loc == loc_end) {  // dynamic scheduling: chains of failing candidates make items uneven
+                    uint32_t base = 0;
+                    if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
+                    base = (uint32_t)__shfl((int)base, (int)(lane & ~(kGroup - 1)));
+                    loc = min(base, n_work);
+                    loc_end = min(base + 4, n_work);
+                }
+                if (loc < loc_end) {
+                    g = a.worklist[loc++];
+                    const uint32_t rs = a.cand_rs[g];
+                    const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
+                    o = a.strand_off[rs];
+                    const uint32_t b0 = a.read_off[r_];
+                    L = a.read_off[r_ + 1] - b0;
+                    ED = (uint32_t)ceil((double)L * a.edit_rate);  // index.rs:281-282
+                    thr_wrapped = 2ull * ED > (uint64_t)L;         // usize wrap of index.rs:406: nothing can pass
+                    thr = L - 2 * ED;
+                    const uint8_t* read = a.bases + b0;
+                    const int pad = (int)(kGroup * R) - (int)L;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        int p = (int)(gl * R + r) - pad;  // read position of this row, < 0 for padding
+                        qc[r] = p >= 0 ? strand_code(read, L, strand, (uint32_t)p) : 6u;
+                        clampRow[r] = p >= 0 ? pk(0, -32768) : pk(0, 0);
+                    }
+                    if (WORD) {
+                        const int seg8 = (int)((L + 7) / 8);  // qP_word, ssw.c:336
+                        bmask = 0;
+#pragma unroll
+                        for (int r = 0; r < (WORD ? R : 1); r++) {
+                            int p = (int)(gl * R + r) - pad;
+                            if (p >= 0 && p % seg8 == 0) bmask |= 1u << r;
+                        }
+                    }
+                } else {
+                    phase = PH_DONE;
+                    have = false;
+                }
+            }
+            if (have) {  // (re)start a sweep: candidate g of the strand whose rows are already loaded
                 const uint4 c = a.cand[g];
-                const uint32_t rs = a.cand_rs[g];
                 const DevBin bin = ix.bins[c.z];
-                const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
-                o = a.strand_off[rs];
-                const uint32_t b0 = a.read_off[r_];
-                const uint32_t L = a.read_off[r_ + 1] - b0;
-                ED = (uint32_t)ceil((double)L * a.edit_rate);  // index.rs:281-282
-                thr_wrapped = 2ull * ED > (uint64_t)L;         // usize wrap of index.rs:406: nothing can pass
-                thr = L - 2 * ED;
-                const uint8_t* read = a.bases + b0;
                 const int pad = (int)(kGroup * R) - (int)L;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
-                    int p = (int)(gl * R + r) - pad;  // read position of this row, < 0 for padding
-                    qc[r] = p >= 0 ? strand_code(read, L, strand, (uint32_t)p) : 6u;
-                    clampRow[r] = p >= 0 ? pk(0, -32768) : pk(0, 0);
+                    int p = (int)(gl * R + r) - pad;
                     h[r] = pk(0, p >= 0 ? -(p + 1) : 0);  // column 0: H = 0, D[i][0] = i
                 }
                 {
@@ -970,14 +998,10 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                     up_prev = pk(0, p0 > 0 ? -p0 : 0);
                 }
                 if (WORD) {
-                    const int seg8 = (int)((L + 7) / 8);  // qP_word, ssw.c:336
-                    bmask = 0;
                     upw_prev = 0;
                     bestw = 0;
 #pragma unroll
                     for (int r = 0; r < (WORD ? R : 1); r++) {
-                        int p = (int)(gl * R + r) - pad;
-                        if (p >= 0 && p % seg8 == 0) bmask |= 1u << r;
                         hw[r] = 0;
                         hwp[r] = 0;
                     }
@@ -1009,8 +1033,6 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                 steps = Wn + kGroup - 1;
                 c_next = ring[(0u - gl) & (kRing - 1)];
                 phase = PH_SWEEP;
-            } else {
-                phase = PH_DONE;
             }
         }
         if (__all(phase == PH_DONE)) break;
@@ -1035,7 +1057,7 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                 const int jl = (int)t - 1 - (int)gl;                       // last column this lane has swept (-1: none)
                 const int jc = min(jl, (int)Wn - 1);
                 const int cols_left = (int)Wn - 1 - jc;
-                const int L_ = (int)(thr + 2 * ED);
+                const int L_ = (int)L;
                 const int pad = (int)(kGroup * R) - L_;
                 int sw_ub = 0, ed_lb = 0x7fff;
 #pragma unroll
@@ -1058,12 +1080,14 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                 }
                 sw_ub = max(sw_ub, (int)Wn - (int)t + (int)kGroup);          // alignments that start in unswept columns
                 if (thr_wrapped || sw_ub < (int)thr || ed_lb > (int)ED) {
-                    if (gl == 0) {
-                        a.cand_status[g] = 1;
-                        const uint32_t nxt = a.cand_next[g];
-                        if (nxt != 0xffffffffu && nxt < maxc) a.worklist_next[atomicAdd(a.wl_next_count, 1u)] = o + nxt;
+                    if (gl == 0) a.cand_status[g] = 1;
+                    const uint32_t nxt = a.cand_next[g];  // next candidate of this TaxId in rank order (index.rs:393)
+                    if (nxt != 0xffffffffu && nxt < maxc) {
+                        g = o + nxt;
+                        phase = PH_CHAIN;
+                    } else {
+                        phase = PH_FETCH;
                     }
-                    phase = PH_FETCH;
                 }
             }
         }
@@ -1133,17 +1157,20 @@ __global__ __launch_bounds__(256) void k_evaluate(DevIndexView ix, EvalArgs a) {
                     if (sw >= 254) sw = w2;  // byte kernel overflowed -> sw_sse2_word's score (ssw.c:789-792)
                 }
                 const bool pass = !thr_wrapped && (uint32_t)sw >= thr && ed <= ED;  // index.rs:406,410
-                if (gl == 0) {
-                    if (pass) {
+                phase = PH_FETCH;
+                if (pass) {
+                    if (gl == 0) {
                         a.out[g] = make_uint4(c_tax, c_gi, c_off, ed);
                         a.cand_status[g] = 2;
-                    } else {
-                        a.cand_status[g] = 1;
-                        const uint32_t nxt = a.cand_next[g];  // next candidate of this TaxId in rank order
-                        if (nxt != 0xffffffffu && nxt < maxc) a.worklist_next[atomicAdd(a.wl_next_count, 1u)] = o + nxt;
+                    }
+                } else {
+                    if (gl == 0) a.cand_status[g] = 1;
+                    const uint32_t nxt = a.cand_next[g];  // next candidate of this TaxId in rank order (index.rs:393)
+                    if (nxt != 0xffffffffu && nxt < maxc) {
+                        g = o + nxt;
+                        phase = PH_CHAIN;
                     }
                 }
-                phase = PH_FETCH;
             }
         }
     }
@@ -1192,15 +1219,18 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     const uint32_t n_work = *a.wl_count;
     const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
                                                : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t stride = gridDim.x * blockDim.x;
     unsigned long long verified = 0, wbytes = 0;
-    for (uint32_t w = tid; w < n_work; w += stride) {
-        const uint32_t g = a.worklist[w];
-        const uint4 c = a.cand[g];
+    for (;;) {
+        uint32_t wbase = 0;
+        if (lane_id() == 0) wbase = atomicAdd(a.wl_cursor, (uint32_t)kWave);  // dynamic: chains make items uneven
+        wbase = __builtin_amdgcn_readfirstlane(wbase);
+        if (wbase >= n_work) break;
+        const uint32_t w = wbase + lane_id();
+        if (w >= n_work) continue;
+        uint32_t g = a.worklist[w];
         const uint32_t rs = a.cand_rs[g];
-        const DevBin bin = ix.bins[c.z];
         const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
+        const uint32_t o = a.strand_off[rs];
         const uint32_t b0 = a.read_off[r_];
         const uint32_t L = a.read_off[r_ + 1] - b0;
         const uint32_t ED = (uint32_t)ceil((double)L * a.edit_rate);
@@ -1226,6 +1256,12 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                 }
             }
             eqA[k] = mA; eqC[k] = mC; eqG[k] = mG; eqT[k] = mT;
+        }
+      for (;;) {  // this candidate, then -- while it fails -- the next one of the same TaxId (index.rs:393)
+        const uint4 c = a.cand[g];
+        const DevBin bin = ix.bins[c.z];
+#pragma unroll
+        for (int k = 0; k < W; k++) {
             Pv[k] = ~0ull;
             Mv[k] = 0;
         }
@@ -1279,11 +1315,13 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
         if (pass) {
             a.out[g] = make_uint4(bin.tax_id, bin.gi, c.x >= bin.start ? c.x - bin.start : 0, ed);
             a.cand_status[g] = 2;
-        } else {
-            a.cand_status[g] = 1;
-            const uint32_t nxt = a.cand_next[g];
-            if (nxt != 0xffffffffu && nxt < maxc) a.worklist_next[atomicAdd(a.wl_next_count, 1u)] = a.strand_off[rs] + nxt;
+            break;
         }
+        a.cand_status[g] = 1;
+        const uint32_t nxt = a.cand_next[g];
+        if (nxt == 0xffffffffu || nxt >= maxc) break;
+        g = o + nxt;
+      }
     }
     for (int d = 32; d > 0; d >>= 1) {
         verified += __shfl_down(verified, d);

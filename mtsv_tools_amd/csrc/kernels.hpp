@@ -30,8 +30,7 @@ struct EvalArgs {
     uint32_t* cand_status;        // 0 not verified, 1 failed, 2 passed
     const uint32_t* worklist;     // candidate indices of this round
     const uint32_t* wl_count;
-    uint32_t* worklist_next;      // filled by failures for the next round
-    uint32_t* wl_next_count;
+    uint32_t* wl_cursor;         // dynamic scheduling: next unclaimed worklist position
     uint4* out;                   // out[candidate] = (tax_id, gi, offset, edit) when it passed
     unsigned long long* n_verified;
     unsigned long long* window_bytes;
