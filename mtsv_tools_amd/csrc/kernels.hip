@@ -897,6 +897,23 @@ __device__ inline int row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v,
 
 __device__ inline uint32_t group_ballot(bool p, uint32_t group) { return (uint32_t)(__ballot(p) >> (group * kGroup)) & 0xffffu; }
 
+// 16 window symbols starting at text[pos] (any alignment) as four little-endian dwords; bytes past
+// the text read as 7.  Aligned dword loads + v_alignbyte.
+__device__ inline uint4 load16(const uint8_t* __restrict__ text, uint32_t n, uint32_t pos) {
+    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(text);
+    const uint32_t w0 = pos >> 2, sh = pos & 3;
+    const uint32_t lastw = (n - 1) >> 2;  // text allocations are padded to a dword multiple
+    uint32_t d[5];
+#pragma unroll
+    for (int k = 0; k < 5; k++) d[k] = (w0 + k <= lastw) ? t32[w0 + k] : 0x07070707u;
+    uint4 r;
+    r.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
+    r.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
+    r.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
+    r.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+    return r;
+}
+
 enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2, PH_CHAIN = 3 };
 
 // One work item = the first candidate of a TaxId of a strand (index into cand[]).  When it fails, the
@@ -911,7 +928,7 @@ enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2, PH_CHAIN = 3 };
 // h = max(hb, up_pre-1); pre = boundary row ? hb : h -- computed here next to the exact score.
 template <int R, bool WORD>
 __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevIndexView ix, EvalArgs a) {
-    __shared__ uint8_t ring_all[256 / kGroup][kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / kGroup][kRing];
     const uint32_t lane = lane_id();
     const uint32_t gl = lane & (kGroup - 1);  // lane inside the group
     uint8_t* ring = ring_all[threadIdx.x / kGroup];
@@ -1014,18 +1031,9 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
                 verified++;
                 wbytes += Wn;
                 const uint32_t lim = min(Wn, kRing);
-                for (uint32_t base = 0; base < lim; base += 4 * kGroup) {
-                    uint8_t v[4];
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        uint32_t col = base + k * kGroup + gl, pos = wstart + col;
-                        v[k] = (col < lim && pos < ix.n) ? ix.text[pos] : (uint8_t)7;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        uint32_t col = base + k * kGroup + gl;
-                        if (col < lim) ring[col] = v[k];
-                    }
+                for (uint32_t base = 0; base < lim; base += 16 * kGroup) {  // 16 symbols per lane per pass
+                    const uint32_t col = base + gl * 16;
+                    if (col < lim) *reinterpret_cast<uint4*>(ring + col) = load16(ix.text, ix.n, wstart + col);
                 }
                 best = pk(0, -32768);
                 last = h[R - 1];  // min over the last row starts at D[L][0] (only lane 15 is read)
@@ -1197,23 +1205,6 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
 // the last row) with Myers' bit-vector recurrence, one lane per candidate, W 64-bit words per
 // column.  Read 'N' matches nothing (index.rs:272-279), reference 'N' matches nothing either.
 // ---------------------------------------------------------------------------------------------
-// 16 window symbols starting at text[pos] (any alignment) as four little-endian dwords; bytes past
-// the text read as 7.  Aligned dword loads + v_alignbyte.
-__device__ inline uint4 load16(const uint8_t* __restrict__ text, uint32_t n, uint32_t pos) {
-    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(text);
-    const uint32_t w0 = pos >> 2, sh = pos & 3;
-    const uint32_t lastw = (n - 1) >> 2;  // text allocations are padded to a dword multiple
-    uint32_t d[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) d[k] = (w0 + k <= lastw) ? t32[w0 + k] : 0x07070707u;
-    uint4 r;
-    r.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
-    r.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
-    r.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
-    r.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
-    return r;
-}
-
 template <int W>
 __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a) {
     const uint32_t n_work = *a.wl_count;
