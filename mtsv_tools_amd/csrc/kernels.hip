@@ -1210,115 +1210,140 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     const uint32_t n_work = *a.wl_count;
     const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
                                                : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
+    const uint32_t lane = lane_id();
     unsigned long long verified = 0, wbytes = 0;
+    // wave-uniform slice of the worklist, claimed 64 items at a time; a lane whose candidate passed
+    // (or whose TaxId chain ended) takes the next item, a lane whose candidate failed keeps its read
+    // and moves to the next candidate of the same TaxId (index.rs:393)
+    uint32_t bnext = 0, bend = 0;
+    bool active = false, exhausted = false;
+    uint32_t g = 0, o = 0, L = 0, ED = 0, strand = 0;
+    bool thr_wrapped = false;
+    uint64_t eqA[W], eqC[W], eqG[W], eqT[W];
     for (;;) {
-        uint32_t wbase = 0;
-        if (lane_id() == 0) wbase = atomicAdd(a.wl_cursor, (uint32_t)kWave);  // dynamic: chains make items uneven
-        wbase = __builtin_amdgcn_readfirstlane(wbase);
-        if (wbase >= n_work) break;
-        const uint32_t w = wbase + lane_id();
-        if (w >= n_work) continue;
-        uint32_t g = a.worklist[w];
-        const uint32_t rs = a.cand_rs[g];
-        const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
-        const uint32_t o = a.strand_off[rs];
-        const uint32_t b0 = a.read_off[r_];
-        const uint32_t L = a.read_off[r_ + 1] - b0;
-        const uint32_t ED = (uint32_t)ceil((double)L * a.edit_rate);
-        const bool thr_wrapped = 2ull * ED > (uint64_t)L;
-        const uint8_t* read = a.bases + b0;
-        // match masks of the FORWARD read; the reverse strand walks the window backwards with
-        // complemented symbols instead (edit distance is invariant under reversing both strings)
-        uint64_t eqA[W], eqC[W], eqG[W], eqT[W], Pv[W], Mv[W];
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            uint64_t mA = 0, mC = 0, mG = 0, mT = 0;
-            for (uint32_t b = 0; b < 64; b += 4) {
-                uint32_t p = k * 64 + b;
-                if (p >= L) break;
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    uint32_t code = p + q < L ? base_code(read[p + q]) : 7u;
-                    uint64_t bit = 1ull << (b + q);
-                    mA |= code == 0 ? bit : 0;
-                    mC |= code == 1 ? bit : 0;
-                    mG |= code == 2 ? bit : 0;
-                    mT |= code == 3 ? bit : 0;
-                }
+        unsigned long long need = __ballot(!active);
+        if (need) {
+            if (bnext == bend && !exhausted) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.wl_cursor, 64u);
+                base = __builtin_amdgcn_readfirstlane(base);
+                bnext = min(base, n_work);
+                bend = min(base + 64u, n_work);
+                exhausted = bnext == bend;
             }
-            eqA[k] = mA; eqC[k] = mC; eqG[k] = mG; eqT[k] = mT;
-        }
-      for (;;) {  // this candidate, then -- while it fails -- the next one of the same TaxId (index.rs:393)
-        const uint4 c = a.cand[g];
-        const DevBin bin = ix.bins[c.z];
-#pragma unroll
-        for (int k = 0; k < W; k++) {
-            Pv[k] = ~0ull;
-            Mv[k] = 0;
-        }
-        const uint32_t Wn = c.y - c.x;
-        const uint32_t last_blk = (L - 1) / 64, last_bit = (L - 1) & 63;
-        int score = (int)L, best = (int)L;  // D[L][0] = L
-        uint4 nxt4 = Wn ? load16(ix.text, ix.n, strand ? (c.y >= 16 ? c.y - 16 : 0) : c.x) : make_uint4(0, 0, 0, 0);
-        for (uint32_t j0 = 0; j0 < Wn; j0 += 16) {
-            const uint4 cur = nxt4;
-            const uint32_t jn = j0 + 16;
-            if (jn < Wn) {  // prefetch the next 16 columns
-                uint32_t pos = strand ? (c.y >= jn + 16 ? c.y - jn - 16 : 0) : c.x + jn;
-                nxt4 = load16(ix.text, ix.n, pos);
-            }
-            const uint32_t lim = min(16u, Wn - j0);
-            // for the reverse walk the chunk holds text[c.y-j0-16 .. c.y-j0): consume from its top; when the
-            // window start clamps at 0 the chunk is aligned to text position 0 instead
-            const uint32_t rev_base = strand ? (c.y >= j0 + 16 ? 0u : (j0 + 16 - c.y)) : 0u;
-            for (uint32_t jj = 0; jj < lim; jj++) {
-                uint32_t bi = strand ? (15u - jj - rev_base) : jj;
-                uint32_t word = bi < 4 ? cur.x : bi < 8 ? cur.y : bi < 12 ? cur.z : cur.w;
-                uint32_t tc = (word >> ((bi & 3) * 8)) & 0xffu;
-                if (strand) tc = tc < 4 ? 3 - tc : tc;  // complement
-                uint64_t hp = 0, hm = 0;  // horizontal delta entering block 0 is 0 (first row all zeros)
+            const uint32_t take = bnext + __popcll(need & ((1ull << lane) - 1));
+            if (!active && take < bend) {
+                g = a.worklist[take];
+                const uint32_t rs = a.cand_rs[g];
+                const uint32_t r_ = a.r0 + (rs >> 1);
+                strand = rs & 1;
+                o = a.strand_off[rs];
+                const uint32_t b0 = a.read_off[r_];
+                L = a.read_off[r_ + 1] - b0;
+                ED = (uint32_t)ceil((double)L * a.edit_rate);
+                thr_wrapped = 2ull * ED > (uint64_t)L;
+                const uint8_t* read = a.bases + b0;
+                // match masks of the FORWARD read; the reverse strand walks the window backwards with
+                // complemented symbols instead (edit distance is invariant under reversing both strings)
 #pragma unroll
                 for (int k = 0; k < W; k++) {
-                    uint64_t Eq = tc == 0 ? eqA[k] : (tc == 1 ? eqC[k] : (tc == 2 ? eqG[k] : (tc == 3 ? eqT[k] : 0ull)));
-                    const uint64_t pv = Pv[k], mv = Mv[k];
-                    const uint64_t Xv = Eq | mv;
-                    Eq |= hm;
-                    const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-                    uint64_t Ph = mv | ~(Xh | pv);
-                    uint64_t Mh = pv & Xh;
-                    int d = (int)((Ph >> last_bit) & 1) - (int)((Mh >> last_bit) & 1);
-                    score += ((uint32_t)k == last_blk) ? d : 0;
-                    const uint64_t op = Ph >> 63, om = Mh >> 63;
-                    Ph = (Ph << 1) | hp;
-                    Mh = (Mh << 1) | hm;
-                    Pv[k] = Mh | ~(Xv | Ph);
-                    Mv[k] = Ph & Xv;
-                    hp = op;
-                    hm = om;
+                    uint64_t mA = 0, mC = 0, mG = 0, mT = 0;
+                    for (uint32_t bq = 0; bq < 64; bq += 4) {
+                        uint32_t p = k * 64 + bq;
+                        if (p >= L) break;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            uint32_t code = p + q < L ? base_code(read[p + q]) : 7u;
+                            uint64_t bit = 1ull << (bq + q);
+                            mA |= code == 0 ? bit : 0;
+                            mC |= code == 1 ? bit : 0;
+                            mG |= code == 2 ? bit : 0;
+                            mT |= code == 3 ? bit : 0;
+                        }
+                    }
+                    eqA[k] = mA; eqC[k] = mC; eqG[k] = mG; eqT[k] = mT;
                 }
-                best = min(best, score);
+                active = true;
+            }
+            bnext = min(bnext + (uint32_t)__popcll(need), bend);
+        }
+        if (!__any(active)) {
+            if (exhausted) break;
+            continue;
+        }
+        if (active) {
+            const uint4 c = a.cand[g];
+            const DevBin bin = ix.bins[c.z];
+            uint64_t Pv[W], Mv[W];
+#pragma unroll
+            for (int k = 0; k < W; k++) {
+                Pv[k] = ~0ull;
+                Mv[k] = 0;
+            }
+            const uint32_t Wn = c.y - c.x;
+            const uint32_t last_blk = (L - 1) / 64, last_bit = (L - 1) & 63;
+            int score = (int)L, best = (int)L;  // D[L][0] = L
+            uint4 nxt4 = Wn ? load16(ix.text, ix.n, strand ? (c.y >= 16 ? c.y - 16 : 0) : c.x) : make_uint4(0, 0, 0, 0);
+            for (uint32_t j0 = 0; j0 < Wn; j0 += 16) {
+                const uint4 cur = nxt4;
+                const uint32_t jn = j0 + 16;
+                if (jn < Wn) {  // prefetch the next 16 columns
+                    uint32_t pos = strand ? (c.y >= jn + 16 ? c.y - jn - 16 : 0) : c.x + jn;
+                    nxt4 = load16(ix.text, ix.n, pos);
+                }
+                const uint32_t lim = min(16u, Wn - j0);
+                // reverse walk: the chunk holds text[c.y-j0-16 .. c.y-j0), consumed from its top; when the
+                // start clamps at text position 0 the chunk is aligned there instead
+                const uint32_t rev_base = strand ? (c.y >= j0 + 16 ? 0u : (j0 + 16 - c.y)) : 0u;
+                for (uint32_t jj = 0; jj < lim; jj++) {
+                    uint32_t bi = strand ? (15u - jj - rev_base) : jj;
+                    uint32_t word = bi < 4 ? cur.x : bi < 8 ? cur.y : bi < 12 ? cur.z : cur.w;
+                    uint32_t tc = (word >> ((bi & 3) * 8)) & 0xffu;
+                    if (strand) tc = tc < 4 ? 3 - tc : tc;  // complement
+                    uint64_t hp = 0, hm = 0;  // horizontal delta entering block 0 is 0 (first row all zeros)
+#pragma unroll
+                    for (int k = 0; k < W; k++) {
+                        uint64_t Eq = tc == 0 ? eqA[k] : (tc == 1 ? eqC[k] : (tc == 2 ? eqG[k] : (tc == 3 ? eqT[k] : 0ull)));
+                        const uint64_t pv = Pv[k], mv = Mv[k];
+                        const uint64_t Xv = Eq | mv;
+                        Eq |= hm;
+                        const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                        uint64_t Ph = mv | ~(Xh | pv);
+                        uint64_t Mh = pv & Xh;
+                        int d = (int)((Ph >> last_bit) & 1) - (int)((Mh >> last_bit) & 1);
+                        score += ((uint32_t)k == last_blk) ? d : 0;
+                        const uint64_t op = Ph >> 63, om = Mh >> 63;
+                        Ph = (Ph << 1) | hp;
+                        Mh = (Mh << 1) | hm;
+                        Pv[k] = Mh | ~(Xv | Ph);
+                        Mv[k] = Ph & Xv;
+                        hp = op;
+                        hm = om;
+                    }
+                    best = min(best, score);
+                }
+            }
+            verified++;
+            wbytes += Wn;
+            const uint32_t ed = (uint32_t)best;
+            const bool pass = !thr_wrapped && ed <= ED;
+            if (pass) {
+                a.out[g] = make_uint4(bin.tax_id, bin.gi, c.x >= bin.start ? c.x - bin.start : 0, ed);
+                a.cand_status[g] = 2;
+                active = false;
+            } else {
+                a.cand_status[g] = 1;
+                const uint32_t nxt = a.cand_next[g];
+                if (nxt == 0xffffffffu || nxt >= maxc) active = false;
+                else g = o + nxt;
             }
         }
-        verified++;
-        wbytes += Wn;
-        const uint32_t ed = (uint32_t)best;
-        const bool pass = !thr_wrapped && ed <= ED;
-        if (pass) {
-            a.out[g] = make_uint4(bin.tax_id, bin.gi, c.x >= bin.start ? c.x - bin.start : 0, ed);
-            a.cand_status[g] = 2;
-            break;
-        }
-        a.cand_status[g] = 1;
-        const uint32_t nxt = a.cand_next[g];
-        if (nxt == 0xffffffffu || nxt >= maxc) break;
-        g = o + nxt;
-      }
     }
     for (int d = 32; d > 0; d >>= 1) {
         verified += __shfl_down(verified, d);
         wbytes += __shfl_down(wbytes, d);
     }
-    if (lane_id() == 0 && verified) {
+    if (lane == 0 && verified) {
         atomicAdd(a.n_verified, verified);
         atomicAdd(a.window_bytes, wbytes);
     }
