@@ -926,12 +926,12 @@ enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2, PH_CHAIN = 3 };
 // gap crosses a stripe boundary (read rows that are multiples of segLen = ceil(L/8)) by one cell only
 // and E never sees the lazy correction.  Row-wise that is: hb = max(0, diag+s, left_pre-1);
 // h = max(hb, up_pre-1); pre = boundary row ? hb : h -- computed here next to the exact score.
-template <int R, bool WORD>
-__global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevIndexView ix, EvalArgs a) {
-    __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / kGroup][kRing];
+template <int R, bool WORD, int GS>
+__global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)) void k_evaluate(DevIndexView ix, EvalArgs a) {
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][kRing];
     const uint32_t lane = lane_id();
-    const uint32_t gl = lane & (kGroup - 1);  // lane inside the group
-    uint8_t* ring = ring_all[threadIdx.x / kGroup];
+    const uint32_t gl = lane & (GS - 1);  // lane inside the group
+    uint8_t* ring = ring_all[threadIdx.x / GS];
     const uint32_t n_work = *a.wl_count;
     const pk16 one = pk(1, 1), miss = pk(-1, -1);
     const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
@@ -965,7 +965,7 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
                 if (loc == loc_end) {  // dynamic scheduling: chains of failing candidates make items uneven
                     uint32_t base = 0;
                     if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
-                    base = (uint32_t)__shfl((int)base, (int)(lane & ~(kGroup - 1)));
+                    base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
                     loc = min(base, n_work);
                     loc_end = min(base + 4, n_work);
                 }
@@ -980,7 +980,7 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
                     thr_wrapped = 2ull * ED > (uint64_t)L;         // usize wrap of index.rs:406: nothing can pass
                     thr = L - 2 * ED;
                     const uint8_t* read = a.bases + b0;
-                    const int pad = (int)(kGroup * R) - (int)L;
+                    const int pad = (int)(GS * R) - (int)L;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
                         int p = (int)(gl * R + r) - pad;  // read position of this row, < 0 for padding
@@ -1004,7 +1004,7 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
             if (have) {  // (re)start a sweep: candidate g of the strand whose rows are already loaded
                 const uint4 c = a.cand[g];
                 const DevBin bin = ix.bins[c.z];
-                const int pad = (int)(kGroup * R) - (int)L;
+                const int pad = (int)(GS * R) - (int)L;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
                     int p = (int)(gl * R + r) - pad;
@@ -1031,14 +1031,14 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
                 verified++;
                 wbytes += Wn;
                 const uint32_t lim = min(Wn, kRing);
-                for (uint32_t base = 0; base < lim; base += 16 * kGroup) {  // 16 symbols per lane per pass
+                for (uint32_t base = 0; base < lim; base += 16 * GS) {  // 16 symbols per lane per pass
                     const uint32_t col = base + gl * 16;
                     if (col < lim) *reinterpret_cast<uint4*>(ring + col) = load16(ix.text, ix.n, wstart + col);
                 }
                 best = pk(0, -32768);
                 last = h[R - 1];  // min over the last row starts at D[L][0] (only lane 15 is read)
                 t = 0;
-                steps = Wn + kGroup - 1;
+                steps = Wn + GS - 1;
                 c_next = ring[(0u - gl) & (kRing - 1)];
                 phase = PH_SWEEP;
             }
@@ -1047,9 +1047,9 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
         if (phase == PH_SWEEP) {
             // windows longer than the ring: once every lane has crossed a half boundary b (lane 15 lags
             // by 15 columns), overwrite columns [b-512, b) with [b+512, b+1024)
-            if (Wn > kRing && t >= kRing / 2 + kGroup && ((t - kGroup) & (kRing / 2 - 1)) == 0) {
-                const uint32_t from = (t - kGroup) + kRing / 2, to = min(Wn, from + kRing / 2);
-                for (uint32_t col = from + gl; col < to; col += kGroup) {
+            if (Wn > kRing && t >= kRing / 2 + GS && ((t - GS) & (kRing / 2 - 1)) == 0) {
+                const uint32_t from = (t - GS) + kRing / 2, to = min(Wn, from + kRing / 2);
+                for (uint32_t col = from + gl; col < to; col += GS) {
                     uint32_t pos = wstart + col;
                     ring[col & (kRing - 1)] = pos < ix.n ? ix.text[pos] : (uint8_t)7;
                 }
@@ -1066,7 +1066,7 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
                 const int jc = min(jl, (int)Wn - 1);
                 const int cols_left = (int)Wn - 1 - jc;
                 const int L_ = (int)L;
-                const int pad = (int)(kGroup * R) - L_;
+                const int pad = (int)(GS * R) - L_;
                 int sw_ub = 0, ed_lb = 0x7fff;
 #pragma unroll
                 for (int r = 0; r < R; r++) {
@@ -1080,13 +1080,13 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
                 }
                 if (gl == 0) ed_lb = min(ed_lb, max(0, L_ - cols_left));  // paths still in the free first row
                 sw_ub = max(sw_ub, (int)best.x);
-                if (gl == kGroup - 1) ed_lb = min(ed_lb, -(int)last.y);     // best of the last row so far
+                if (gl == GS - 1) ed_lb = min(ed_lb, -(int)last.y);     // best of the last row so far
 #pragma unroll
-                for (int d = 1; d < (int)kGroup; d <<= 1) {
+                for (int d = 1; d < GS; d <<= 1) {
                     sw_ub = max(sw_ub, __shfl_xor(sw_ub, d));
                     ed_lb = min(ed_lb, __shfl_xor(ed_lb, d));
                 }
-                sw_ub = max(sw_ub, (int)Wn - (int)t + (int)kGroup);          // alignments that start in unswept columns
+                sw_ub = max(sw_ub, (int)Wn - (int)t + GS);          // alignments that start in unswept columns
                 if (thr_wrapped || sw_ub < (int)thr || ed_lb > (int)ED) {
                     if (gl == 0) a.cand_status[g] = 1;
                     const uint32_t nxt = a.cand_next[g];  // next candidate of this TaxId in rank order (index.rs:393)
@@ -1106,9 +1106,11 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
             const int j = (int)t - (int)gl;
             c_next = ring[(uint32_t)(j + 1) & (kRing - 1)];
             int in_bits = row_shr1(pk_bits(h[R - 1]));
-            const pk16 in = pk_from_bits(in_bits);  // lane 0 of the row reads 0: H = 0, D[0][j] = 0
+            if (GS < 16 && gl == 0) in_bits = 0;  // a DPP row holds two groups: cut the shift at the group edge
+            const pk16 in = pk_from_bits(in_bits);  // lane 0 of the group reads 0: H = 0, D[0][j] = 0
             int inw = 0;
             if (WORD) inw = row_shr1((hw[(WORD ? R : 1) - 1] << 16) | hwp[(WORD ? R : 1) - 1]);  // (post, pre) of the row above
+            if (WORD && GS < 16 && gl == 0) inw = 0;
             if (j >= 0 && j < (int)Wn) {
                 const pk16 mvc = c == kCodeN ? pk(1, -1) : pk(1, 0);  // N/N: +1 in SW, never a match in edit distance
                 pk16 diag = up_prev, up = in;
@@ -1150,18 +1152,14 @@ __global__ __launch_bounds__(256, (WORD || R > 10) ? 1 : 5) void k_evaluate(DevI
           }
             if (t >= steps) {
                 int sw = best.x;
-                sw = max(sw, __shfl_xor(sw, 1));
-                sw = max(sw, __shfl_xor(sw, 2));
-                sw = max(sw, __shfl_xor(sw, 4));
-                sw = max(sw, __shfl_xor(sw, 8));
-                const int lastv = __shfl((int)last.y, (int)(lane | (kGroup - 1)));
+#pragma unroll
+                for (int d = 1; d < GS; d <<= 1) sw = max(sw, __shfl_xor(sw, d));
+                const int lastv = __shfl((int)last.y, (int)(lane | (GS - 1)));
                 const uint32_t ed = (uint32_t)(-lastv);
                 if (WORD) {
                     int w2 = bestw;
-                    w2 = max(w2, __shfl_xor(w2, 1));
-                    w2 = max(w2, __shfl_xor(w2, 2));
-                    w2 = max(w2, __shfl_xor(w2, 4));
-                    w2 = max(w2, __shfl_xor(w2, 8));
+#pragma unroll
+                    for (int d = 1; d < GS; d <<= 1) w2 = max(w2, __shfl_xor(w2, d));
                     if (sw >= 254) sw = w2;  // byte kernel overflowed -> sw_sse2_word's score (ssw.c:789-792)
                 }
                 const bool pass = !thr_wrapped && (uint32_t)sw >= thr && ed <= ED;  // index.rs:406,410
@@ -1482,25 +1480,22 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
 }
 
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
-    // 16 candidates per 256-thread block in flight; persistent groups stride over the worklist
-    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 16), 256 * 8));
-    uint32_t R = (max_len + kGroup - 1) / kGroup;
-#define EVAL_CASE(RR, WW) hipLaunchKernelGGL((k_evaluate<RR, WW>), dim3(blocks), dim3(256), 0, s, ix, a)
-    if (max_len < 254) {
-        if (R <= 2) EVAL_CASE(2, false);
-        else if (R <= 4) EVAL_CASE(4, false);
-        else if (R <= 5) EVAL_CASE(5, false);
-        else if (R <= 7) EVAL_CASE(7, false);
-        else if (R <= 8) EVAL_CASE(8, false);
-        else if (R <= 10) EVAL_CASE(10, false);
-        else if (R <= 13) EVAL_CASE(13, false);
-        else EVAL_CASE(16, false);
-    } else {
-        if (R <= 16) EVAL_CASE(16, true);
-        else if (R <= 20) EVAL_CASE(20, true);
-        else if (R <= 24) EVAL_CASE(24, true);
-        else EVAL_CASE(32, true);
-    }
+    // persistent 16-lane groups claim candidates from the worklist
+#define EVAL_CASE(RR, WW, GG) hipLaunchKernelGGL((k_evaluate<RR, WW, GG>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256 / GG), 256 * 8))), dim3(256), 0, s, ix, a)
+    // (8-lane groups, 19 rows per lane, were measured slower for 150-base reads: 21.2 vs 19.2 ms per 1 M reads;
+    //  fewer instructions but only 3 wavefronts per SIMD and twice the fetch stalls per wavefront)
+    if (max_len <= 32) EVAL_CASE(2, false, 16);
+    else if (max_len <= 64) EVAL_CASE(4, false, 16);
+    else if (max_len <= 80) EVAL_CASE(5, false, 16);
+    else if (max_len <= 112) EVAL_CASE(7, false, 16);
+    else if (max_len <= 128) EVAL_CASE(8, false, 16);
+    else if (max_len <= 160) EVAL_CASE(10, false, 16);
+    else if (max_len <= 208) EVAL_CASE(13, false, 16);
+    else if (max_len < 254) EVAL_CASE(16, false, 16);
+    else if (max_len <= 256) EVAL_CASE(16, true, 16);
+    else if (max_len <= 320) EVAL_CASE(20, true, 16);
+    else if (max_len <= 384) EVAL_CASE(24, true, 16);
+    else EVAL_CASE(32, true, 16);
 #undef EVAL_CASE
 }
 
