@@ -940,7 +940,7 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
     uint32_t phase = PH_FETCH;
     uint32_t loc = 0, loc_end = 0;  // this group's slice of the worklist, refilled 4 items at a time
     uint32_t g = 0, o = 0, ED = 0, thr = 0, L = 0;
-    bool thr_wrapped = false;
+    bool thr_wrapped = false, hopeless = false;
     uint32_t qc[R];
     pk16 clampRow[R];
     uint32_t t = 0, steps = 0, Wn = 0, wstart = 0, c_next = 7;
@@ -996,10 +996,32 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
                             if (p >= 0 && p % seg8 == 0) bmask |= 1u << r;
                         }
                     }
+                    // an N of the read never matches in the edit-distance recurrence (index.rs:272-279):
+                    // edits >= #N.  More N than the tolerance: no candidate of this strand can pass :410
+                    int nn = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) nn += qc[r] == kCodeN;
+#pragma unroll
+                    for (int d = 1; d < GS; d <<= 1) nn += __shfl_xor(nn, d);
+                    hopeless = thr_wrapped || (uint32_t)nn > ED;
                 } else {
                     phase = PH_DONE;
                     have = false;
                 }
+            }
+            if (have && hopeless) {  // rejected without a sweep; the reference still ran its prefilter on it
+                const uint4 c = a.cand[g];
+                verified++;
+                wbytes += c.y - c.x;
+                if (gl == 0) a.cand_status[g] = 1;
+                const uint32_t nxt = a.cand_next[g];
+                if (nxt != 0xffffffffu && nxt < maxc) {
+                    g = o + nxt;
+                    phase = PH_CHAIN;
+                } else {
+                    phase = PH_FETCH;
+                }
+                have = false;
             }
             if (have) {  // (re)start a sweep: candidate g of the strand whose rows are already loaded
                 const uint4 c = a.cand[g];
@@ -1216,7 +1238,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     uint32_t bnext = 0, bend = 0;
     bool active = false, exhausted = false;
     uint32_t g = 0, o = 0, L = 0, ED = 0, strand = 0;
-    bool thr_wrapped = false;
+    bool thr_wrapped = false, hopeless = false;
     uint64_t eqA[W], eqC[W], eqG[W], eqT[W];
     for (;;) {
         unsigned long long need = __ballot(!active);
@@ -1261,6 +1283,11 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     }
                     eqA[k] = mA; eqC[k] = mC; eqG[k] = mG; eqT[k] = mT;
                 }
+                // edits >= number of read positions that match nothing (N): see k_evaluate
+                uint32_t matchable = 0;
+#pragma unroll
+                for (int k = 0; k < W; k++) matchable += __popcll(eqA[k] | eqC[k] | eqG[k] | eqT[k]);
+                hopeless = thr_wrapped || L - matchable > ED;
                 active = true;
             }
             bnext = min(bnext + (uint32_t)__popcll(need), bend);
@@ -1269,7 +1296,15 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             if (exhausted) break;
             continue;
         }
-        if (active) {
+        if (active && hopeless) {  // no sweep needed: every candidate of this strand fails
+            const uint4 c = a.cand[g];
+            verified++;
+            wbytes += c.y - c.x;
+            a.cand_status[g] = 1;
+            const uint32_t nxt = a.cand_next[g];
+            if (nxt == 0xffffffffu || nxt >= maxc) active = false;
+            else g = o + nxt;
+        } else if (active) {
             const uint4 c = a.cand[g];
             const DevBin bin = ix.bins[c.z];
             uint64_t Pv[W], Mv[W];
