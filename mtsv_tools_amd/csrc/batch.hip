@@ -65,7 +65,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
 Batch::~Batch() {
     (void)hipSetDevice(di->device);
     (void)hipStreamSynchronize(stream);
-    for (void* p : {(void*)d_bases, (void*)d_read_off, (void*)d_seed_lo, (void*)d_seed_cnt, (void*)d_strand_hits,
+    for (void* p : {(void*)d_bases, (void*)d_read_off, (void*)d_seed_lo, (void*)d_seed_cnt, (void*)d_seed_pre, (void*)d_strand_hits,
                     (void*)d_strand_nseeds, (void*)d_strand_off, (void*)d_strand_ncand, (void*)d_worklist,
                     (void*)d_strand_nout, (void*)d_out_off, (void*)d_tile_sums, (void*)d_counters, (void*)d_hit_row,
                     (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand, (void*)d_out,
@@ -127,10 +127,12 @@ void Batch::run(const mtsv_params& p) {
         if (slots > seed_cap) {
             (void)hipFree(d_seed_lo);
             (void)hipFree(d_seed_cnt);
-            d_seed_lo = d_seed_cnt = nullptr;
+            (void)hipFree(d_seed_pre);
+            d_seed_lo = d_seed_cnt = d_seed_pre = nullptr;
             uint64_t dummy = 0;
             dev_alloc(&d_seed_lo, slots, &dummy);
             dev_alloc(&d_seed_cnt, slots, &dummy);
+            dev_alloc(&d_seed_pre, slots, &dummy);
             seed_cap = slots;
         }
         // ---- seeds ----
@@ -139,7 +141,7 @@ void Batch::run(const mtsv_params& p) {
         HIP_CHECK(hipEventRecord(ev[1], stream));
         if (max_ns)
             launch_thin(stream, d_read_off, (uint32_t)r0, nr, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
-                        d_strand_hits, d_strand_nseeds);
+                        d_seed_pre, d_strand_hits, d_strand_nseeds);
         else {
             HIP_CHECK(hipMemsetAsync(d_strand_hits, 0, (uint64_t)nstr * 4, stream));
             HIP_CHECK(hipMemsetAsync(d_strand_nseeds, 0, (uint64_t)nstr * 4, stream));
@@ -160,7 +162,8 @@ void Batch::run(const mtsv_params& p) {
         stats.n_seed_slots += slots;
         stats.n_seed_hits += total_hits;
         // ---- locate ----
-        launch_expand(stream, v, nstr, max_ns, G, d_seed_lo, d_seed_cnt, d_strand_off, d_hit_row, d_hit_ref, d_hit_q);
+        launch_expand(stream, v, nstr, max_ns, G, d_seed_lo, d_seed_cnt, d_seed_pre, d_strand_off, d_hit_row, d_hit_ref,
+                      d_hit_q);
         HIP_CHECK(hipEventRecord(ev[3], stream));
         if (!v.sa_full)
             launch_locate(stream, v, (uint32_t)total_hits, d_strand_off + nstr, d_hit_row, d_hit_ref,

@@ -17,7 +17,7 @@ struct Batch {
 
     uint8_t* d_bases = nullptr;
     uint32_t* d_read_off = nullptr;
-    uint32_t *d_seed_lo = nullptr, *d_seed_cnt = nullptr;
+    uint32_t *d_seed_lo = nullptr, *d_seed_cnt = nullptr, *d_seed_pre = nullptr;
     uint64_t seed_cap = 0;
     uint32_t *d_strand_hits = nullptr, *d_strand_nseeds = nullptr, *d_strand_off = nullptr, *d_strand_ncand = nullptr,
              *d_worklist = nullptr, *d_strand_nout = nullptr, *d_out_off = nullptr;

@@ -5,7 +5,7 @@
 //   k_search    lane per (read, strand, seed): FMIndex::backward_search           index.rs:305
 //   k_thin      lane per strand: adaptive seed thinning / max_hits filter         index.rs:293-344,354
 //   scan        exclusive scan of per-strand seed-hit counts
-//   k_expand    lane per strand: SA rows of every kept seed (Interval::occ)       index.rs:347-352
+//   k_expand    lane per kept seed: its SA rows / text positions (Interval::occ)  index.rs:347-352
 //   k_locate    lane per seed hit with wavefront refill: SampledSuffixArray::get  index.rs:347
 //   k_coalesce  wavefront per strand: sort, coalesce_seed_sites, min_seeds, rank  index.rs:358-369,435-487
 //   k_evaluate  16-lane group per candidate: SW prefilter + edit distance         index.rs:401-410,
@@ -147,7 +147,8 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
 __global__ __launch_bounds__(256) void k_thin(const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t n_reads,
                                               uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits,
                                               uint64_t tune_max_hits, uint32_t* __restrict__ seed_cnt,
-                                              uint32_t* __restrict__ strand_hits, uint32_t* __restrict__ strand_nseeds) {
+                                              uint32_t* __restrict__ seed_pre, uint32_t* __restrict__ strand_hits,
+                                              uint32_t* __restrict__ strand_nseeds) {
     uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
     if (rs >= n_reads * 2) return;
     uint32_t r = r0 + (rs >> 1);
@@ -156,9 +157,11 @@ __global__ __launch_bounds__(256) void k_thin(const uint32_t* __restrict__ read_
     uint64_t next_offset = 0, seed_interval = G;
     uint32_t total = 0, nseeds = 0;
     uint32_t* cnt = seed_cnt + (uint64_t)rs * max_ns;
+    uint32_t* pre = seed_pre + (uint64_t)rs * max_ns;
     for (uint32_t j = 0; j < ns; j++) {
         uint64_t offset = (uint64_t)j * G;
         uint32_t c = cnt[j];
+        pre[j] = total;  // hits of the strand's earlier kept seeds (k_expand's output offset)
         if (offset < next_offset) {  // index.rs:300-302
             if (c) cnt[j] = 0;
             continue;
@@ -268,27 +271,26 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __r
 // ---------------------------------------------------------------------------------------------
 // K1c: expand kept seeds into SA rows (or straight into text positions with the full SA)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_expand(DevIndexView ix, uint32_t n_strands, uint32_t max_ns, uint32_t G,
+__global__ __launch_bounds__(256) void k_expand(DevIndexView ix, uint64_t n_slots, uint32_t max_ns, uint32_t G,
                                                 const uint32_t* __restrict__ seed_lo,
                                                 const uint32_t* __restrict__ seed_cnt,
+                                                const uint32_t* __restrict__ seed_pre,
                                                 const uint32_t* __restrict__ strand_off,
                                                 uint32_t* __restrict__ hit_row, uint32_t* __restrict__ hit_ref,
                                                 uint32_t* __restrict__ hit_q) {
-    uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rs >= n_strands) return;
-    uint32_t o = strand_off[rs], end = strand_off[rs + 1];
-    if (o == end) return;
-    const uint32_t* lo = seed_lo + (uint64_t)rs * max_ns;
-    const uint32_t* cnt = seed_cnt + (uint64_t)rs * max_ns;
-    for (uint32_t j = 0; o < end; j++) {
-        uint32_t c = cnt[j], l = lo[j];
-        for (uint32_t i = 0; i < c; i++, o++) {
-            if (ix.sa_full)
-                hit_ref[o] = ix.sa_full[l + i];
-            else
-                hit_row[o] = l + i;
-            hit_q[o] = j * G;
-        }
+    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (slot >= n_slots) return;
+    const uint32_t c = seed_cnt[slot];
+    if (!c) return;
+    const uint32_t rs = (uint32_t)(slot / max_ns), j = (uint32_t)(slot % max_ns);
+    uint32_t o = strand_off[rs] + seed_pre[slot];
+    const uint32_t l = seed_lo[slot], q = j * G;
+    for (uint32_t i = 0; i < c; i++, o++) {
+        if (ix.sa_full)
+            hit_ref[o] = ix.sa_full[l + i];
+        else
+            hit_row[o] = l + i;
+        hit_q[o] = q;
     }
 }
 
@@ -1450,10 +1452,10 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
 }
 
 void launch_thin(hipStream_t s, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, uint32_t max_ns, uint32_t K,
-                 uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* strand_hits,
+                 uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre, uint32_t* strand_hits,
                  uint32_t* strand_nseeds) {
     hipLaunchKernelGGL(k_thin, dim3(cdiv((uint64_t)n_reads * 2, 256)), dim3(256), 0, s, read_off, r0, n_reads, max_ns, K,
-                       G, max_hits, tune, seed_cnt, strand_hits, strand_nseeds);
+                       G, max_hits, tune, seed_cnt, seed_pre, strand_hits, strand_nseeds);
 }
 
 void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_sums, uint64_t* total, uint32_t* out) {
@@ -1465,9 +1467,11 @@ void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_s
 uint32_t scan_tiles(uint32_t n) { return cdiv(n ? n : 1, kScanTile); }
 
 void launch_expand(hipStream_t s, const DevIndexView& ix, uint32_t n_strands, uint32_t max_ns, uint32_t G,
-                   const uint32_t* seed_lo, const uint32_t* seed_cnt, const uint32_t* strand_off, uint32_t* hit_row,
-                   uint32_t* hit_ref, uint32_t* hit_q) {
-    hipLaunchKernelGGL(k_expand, dim3(cdiv(n_strands, 256)), dim3(256), 0, s, ix, n_strands, max_ns, G, seed_lo, seed_cnt,
+                   const uint32_t* seed_lo, const uint32_t* seed_cnt, const uint32_t* seed_pre, const uint32_t* strand_off,
+                   uint32_t* hit_row, uint32_t* hit_ref, uint32_t* hit_q) {
+    uint64_t n_slots = (uint64_t)n_strands * max_ns;
+    if (!n_slots) return;
+    hipLaunchKernelGGL(k_expand, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, ix, n_slots, max_ns, G, seed_lo, seed_cnt, seed_pre,
                        strand_off, hit_row, hit_ref, hit_q);
 }
 

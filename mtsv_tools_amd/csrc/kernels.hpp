@@ -41,14 +41,14 @@ constexpr uint32_t kMaxReadLen = 512;  // 16 lanes x 32 read rows per lane in k_
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt);
 void launch_thin(hipStream_t s, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, uint32_t max_ns, uint32_t K,
-                 uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* strand_hits,
+                 uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre, uint32_t* strand_hits,
                  uint32_t* strand_nseeds);
 // out has n+1 entries (out[n] = total); tile_sums needs scan_tiles(n) entries
 void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_sums, uint64_t* total, uint32_t* out);
 uint32_t scan_tiles(uint32_t n);
 void launch_expand(hipStream_t s, const DevIndexView& ix, uint32_t n_strands, uint32_t max_ns, uint32_t G,
-                   const uint32_t* seed_lo, const uint32_t* seed_cnt, const uint32_t* strand_off, uint32_t* hit_row,
-                   uint32_t* hit_ref, uint32_t* hit_q);
+                   const uint32_t* seed_lo, const uint32_t* seed_cnt, const uint32_t* seed_pre, const uint32_t* strand_off,
+                   uint32_t* hit_row, uint32_t* hit_ref, uint32_t* hit_q);
 void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_host, const uint32_t* total_hits_dev,
                    const uint32_t* hit_row, uint32_t* hit_ref, unsigned long long* lf_steps);
 void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,

@@ -88,3 +88,37 @@ def test_cli_read_offset_and_resume(tmp_path):
     bad = tmp_path / "bad.txt"
     bad.write_text("no colon here\n")
     assert run("--fasta", fa, "-i", idx, "-m", str(bad)).returncode == 4
+
+
+@pytest.mark.gpu
+def test_chunk_mode_binner_then_collapse_equals_oracle_per_chunk(tmp_path):
+    """BASELINE config 5 on one GPU: the database split into index chunks, the same reads binned
+    against every chunk, results merged with mtsv-collapse == per-chunk CPU runs merged the same way."""
+    import helpers
+    from oracle import oracle as O
+
+    entries, gene, unit = helpers.tricky_db(seed=7)
+    reads = [r for r in helpers.tricky_reads(entries, gene, unit, seed=21, n_each=25) if 0 < len(r) <= 253]
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "w", encoding="latin-1") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@q{i}\n{r.decode('latin-1')}\n+\n{'I' * len(r)}\n")
+    bases, off = helpers.reads_to_batch(reads)
+    collapse = os.path.join(ROOT, "mtsv_tools_amd", "bin", "mtsv-collapse")
+    gpu_files, cpu_files = [], []
+    for c in range(3):
+        chunk = entries[c::3]
+        idx = tmp_path / f"chunk{c}.idx"
+        M.MGIndex.build(chunk, threads=2).write(str(idx))
+        out = tmp_path / f"gpu{c}.txt"
+        assert run("--fastq", str(fq), "-i", str(idx), "-m", str(out), "--output-format", "long").returncode == 0
+        gpu_files.append(str(out))
+        hits, _ = O.Index.read(str(idx)).bin_batch(bases, off, threads=4)
+        cpu = tmp_path / f"cpu{c}.txt"
+        cpu.write_text("".join(O.format_line(f"q{r}", hits[hits["read"] == r], True) for r in range(len(reads))))
+        cpu_files.append(str(cpu))
+    for mode in ("taxid", "taxid-gi"):
+        a, b = tmp_path / f"g_{mode}.txt", tmp_path / f"c_{mode}.txt"
+        assert subprocess.run([collapse, "-o", str(a), "--mode", mode, *gpu_files]).returncode == 0
+        assert subprocess.run([collapse, "-o", str(b), "--mode", mode, *cpu_files]).returncode == 0
+        assert a.read_text() == b.read_text() and len(a.read_text()) > 200
