@@ -285,9 +285,9 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
         v.sa_full = di->d_sa_full;
     }
     if (!(flags & 2u /* MTSV_DEV_NO_KMER_TABLE */)) {
-        // table size ~ index size: 4^k entries of 8 B for 4^k <= n, capped at k = 14 (2 GiB)
+        // table size ~ index size: 4^k entries of 8 B for 4^k <= n, capped at k = 15 (8 GiB)
         uint32_t k = 1;
-        while (k < 14 && (1ull << (2 * (k + 1))) <= (uint64_t)n) k++;
+        while (k < 15 && (1ull << (2 * (k + 1))) <= (uint64_t)n) k++;
         if (const char* e = getenv("MTSV_KMER_K")) {
             int kk = atoi(e);
             if (kk >= 1 && kk <= 15) k = (uint32_t)kk;
