@@ -8,6 +8,11 @@
 #include <zlib.h>
 
 #include <cerrno>
+#include <condition_variable>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -364,61 +369,122 @@ int main(int argc, char** argv) {
     struct timespec w0;
     clock_gettime(CLOCK_MONOTONIC, &w0);
 
-    std::vector<uint8_t> bases;
-    std::vector<uint64_t> off{0};
-    std::string ids;
-    std::vector<uint64_t> id_off{0};
-    Record r;
-    uint64_t skipped = 0, total = 0;
-    auto flush = [&]() -> int {
-        if (off.size() == 1) return 0;
+    // Three overlapped stages (the reference overlaps producer / workers / joiner the same way,
+    // vendor/cue/src/lib.rs:45-105): a reader thread parses FASTX into batches, this thread runs the
+    // batches on the GPU, a writer thread formats and writes the result lines in input order.
+    struct Work {
+        std::vector<uint8_t> bases;
+        std::vector<uint64_t> off{0};
+        std::string ids;
+        std::vector<uint64_t> id_off{0};
         mtsv_hit* hits = nullptr;
-        uint64_t nh = 0;
-        if (mtsv_bin_batch(ix, a.device, bases.data(), off.data(), off.size() - 1, &p, &hits, &nh) != MTSV_OK) {
-            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
-            return 2;
-        }
-        char* text = nullptr;
-        uint64_t len = 0;
-        int rc = mtsv_format_results(hits, nh, ids.data(), id_off.data(), off.size() - 1, long_fmt, &text, &len);
-        mtsv_hits_free(hits);
-        if (rc != MTSV_OK) {
-            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
-            return 2;
-        }
-        bool ok = len == 0 || fwrite(text, 1, len, out) == len;
-        mtsv_free(text);
-        if (!ok) {
-            logmsg("ERROR", "Error writing to result file");
-            return 11;
-        }
-        total += off.size() - 1;
-        logmsg("DEBUG", "taxonomic binning: " + std::to_string(total) + " reads done");
-        bases.clear();
-        off.assign(1, 0);
-        ids.clear();
-        id_off.assign(1, 0);
-        return 0;
+        uint64_t n_hits = 0;
     };
-    while (rd.next(r)) {
-        if (skipped < read_offset) {
-            skipped++;
+    struct Queue {
+        std::mutex mu;
+        std::condition_variable cv;
+        std::deque<std::unique_ptr<Work>> q;
+        bool closed = false;
+        size_t cap = 2;
+        void push(std::unique_ptr<Work> w) {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return q.size() < cap || closed; });
+            q.push_back(std::move(w));
+            cv.notify_all();
+        }
+        std::unique_ptr<Work> pop() {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return !q.empty() || closed; });
+            if (q.empty()) return nullptr;
+            auto w = std::move(q.front());
+            q.pop_front();
+            cv.notify_all();
+            return w;
+        }
+        void close() {
+            std::lock_guard<std::mutex> lk(mu);
+            closed = true;
+            cv.notify_all();
+        }
+    };
+    Queue parsed, done;
+    std::mutex err_mu;
+    int exit_code = 0;
+    auto set_code = [&](int c) {
+        std::lock_guard<std::mutex> lk(err_mu);
+        if (!exit_code) exit_code = c;
+    };
+    auto failed = [&] {
+        std::lock_guard<std::mutex> lk(err_mu);
+        return exit_code != 0;
+    };
+
+    std::thread reader([&] {
+        auto w = std::make_unique<Work>();
+        Record r;
+        uint64_t skipped = 0;
+        while (!failed() && rd.next(r)) {
+            if (skipped < read_offset) {
+                skipped++;
+                continue;
+            }
+            w->bases.insert(w->bases.end(), r.seq.begin(), r.seq.end());
+            w->off.push_back(w->bases.size());
+            w->ids += r.id;
+            w->ids.push_back('\0');
+            w->id_off.push_back(w->ids.size());
+            if (w->off.size() - 1 >= a.batch_reads || w->bases.size() >= (1ull << 30)) {
+                parsed.push(std::move(w));
+                w = std::make_unique<Work>();
+            }
+        }
+        if (rd.error) {
+            logmsg("ERROR", "Unable to read from input file: " + rd.err_msg);
+            set_code(12);  // binner.rs:81-84
+        } else if (w->off.size() > 1) {
+            parsed.push(std::move(w));
+        }
+        parsed.close();
+    });
+
+    std::thread writer([&] {
+        uint64_t total = 0;
+        while (auto w = done.pop()) {
+            char* text = nullptr;
+            uint64_t len = 0;
+            int rc = mtsv_format_results(w->hits, w->n_hits, w->ids.data(), w->id_off.data(), w->off.size() - 1, long_fmt, &text, &len);
+            mtsv_hits_free(w->hits);
+            if (rc != MTSV_OK) {
+                logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+                set_code(2);
+                continue;
+            }
+            bool ok = len == 0 || fwrite(text, 1, len, out) == len;
+            mtsv_free(text);
+            if (!ok) {
+                logmsg("ERROR", "Error writing to result file");
+                set_code(11);  // binner.rs:136-139
+                continue;
+            }
+            total += w->off.size() - 1;
+            logmsg("DEBUG", "taxonomic binning: " + std::to_string(total) + " reads done");
+        }
+    });
+
+    while (auto w = parsed.pop()) {
+        if (failed()) continue;  // drain
+        if (mtsv_bin_batch(ix, a.device, w->bases.data(), w->off.data(), w->off.size() - 1, &p, &w->hits, &w->n_hits) != MTSV_OK) {
+            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+            set_code(2);
             continue;
         }
-        bases.insert(bases.end(), r.seq.begin(), r.seq.end());
-        off.push_back(bases.size());
-        ids += r.id;
-        ids.push_back('\0');
-        id_off.push_back(ids.size());
-        if (off.size() - 1 >= a.batch_reads || bases.size() >= (1ull << 30)) {
-            if (int rc = flush()) return rc;
-        }
+        std::vector<uint8_t>().swap(w->bases);  // the writer needs only ids and hits
+        done.push(std::move(w));
     }
-    if (rd.error) {
-        logmsg("ERROR", "Unable to read from input file: " + rd.err_msg);
-        return 12;  // binner.rs:81-84
-    }
-    if (int rc = flush()) return rc;
+    done.close();
+    reader.join();
+    writer.join();
+    if (exit_code) return exit_code;
     if (fclose(out) != 0) {
         logmsg("ERROR", "Error writing to result file");
         return 11;
