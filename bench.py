@@ -206,6 +206,11 @@ def main():
                "sample": f"first {ns} reads of rank 0's batch, oracle/libmtsv_oracle.so (reference layout: byte BWT, "
                          f"Occ k=64, SA s=32, emulated striped SW, full-matrix edit DP), {cores} OpenMP threads, {dt:.1f} s"}
         stage_bytes, ctr_per = algorithmic_bytes(ctr, ns)
+        # the reference's default thread count (-t 4, src/bin/mtsv-binner.rs:62) on a quarter of the sample
+        ns4 = max(1, ns // 4)
+        t0 = time.perf_counter()
+        oix.bin_batch(bases[: ns4 * read_len], off[: ns4 + 1], O.default_params(), threads=4)
+        cpu["value_4_threads"] = ns4 / (time.perf_counter() - t0)
         g = hits[hits["read"] < ns]
         same = len(g) == len(ohits) and all(np.array_equal(g[f], ohits[f]) for f in
                                             ("read", "tax_id", "gi", "edit", "strand", "offset"))
