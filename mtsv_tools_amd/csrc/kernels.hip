@@ -79,10 +79,12 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
             const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
             const uint32_t w0 = s0 >> 2, sh = s0 & 3;
             uint32_t d[9];
+            const uint32_t nd = (K + 3) / 4;  // dwords that hold seed bytes (wave-uniform)
 #pragma unroll
-            for (int k = 0; k < 9; k++) d[k] = b32[w0 + k];
+            for (int k = 0; k < 9; k++) d[k] = (uint32_t)k <= nd ? b32[w0 + k] : 0u;
 #pragma unroll
             for (int k = 0; k < 8; k++) {
+                if ((uint32_t)k >= nd) break;
                 uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
