@@ -30,6 +30,8 @@ PARAM_SETS = {
     "one_assignment": dict(max_assignments=1),
     "two_candidates": dict(max_candidates=2),
     "big_seed": dict(seed_size=31, seed_interval=7),
+    "seed_over_32": dict(seed_size=40, seed_interval=9),          # k_search's byte-wise path
+    "seed_below_table": dict(seed_size=5, seed_interval=20, max_hits=400, tune_max_hits=100),  # shorter than the k-mer table
 }
 
 
@@ -104,6 +106,57 @@ def test_edit_first_order_gives_identical_hits(tricky, pname):
         b.run(mp)
         assert_same_hits(b.download(), want)
         b.close()
+
+
+def test_mega_tandem_repeat_tens_of_thousands_of_hits_per_strand(tmp_path):
+    """a 400-copy tandem repeat with dense short seeds: > 8192 seed hits per strand (bitonic sort in
+    L2-resident scratch), one merged candidate window of ~20 kb (LDS ring refill in the sweep),
+    thousands of hits thinned by tune_max_hits"""
+    import random
+    rng = random.Random(5)
+    unit = helpers.rnd_seq(rng, 53)
+    flank = lambda: helpers.rnd_seq(rng, 700)
+    entries = [(7, 1, flank() + unit * 400 + flank()), (9, 2, flank() + unit * 30 + flank()), (9, 3, helpers.rnd_seq(rng, 3000))]
+    ix = M.MGIndex.build(entries, threads=2)
+    p = str(tmp_path / "t.idx")
+    ix.write(p)
+    orc = O.Index.read(p)
+    rep = unit * 6
+    reads = [helpers.mutate(rng, rep[s:s + 150], rng.randrange(0, 8)) for s in range(0, 60, 7)]
+    reads += [helpers.revcomp(r) for r in reads[:4]] + [entries[0][2][600:750], entries[2][2][100:250]]
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    for over in (dict(seed_size=11, seed_interval=2, max_hits=100000, tune_max_hits=100000),
+                 dict(seed_size=11, seed_interval=2, max_hits=100000, tune_max_hits=300),
+                 dict(seed_size=14, seed_interval=5, max_hits=100000, tune_max_hits=100000, min_seed=0.2)):
+        mp, op = both_params(**over)
+        want, ctr = orc.bin_batch(bases, off, op, threads=8)
+        b = M.Batch(ix, 0, len(reads), len(bases), max_hits_ws=4_000_000)
+        b.upload(bases, off)
+        b.run(mp)
+        st = b.stats()
+        assert st["n_seed_hits"] == ctr["H"] and st["n_candidates"] == ctr["n_cand"]
+        if over["tune_max_hits"] == 100000 and over["seed_size"] == 11:
+            assert st["n_seed_hits"] / (2 * len(reads)) > 8192  # the global-scratch path is really taken
+            assert st["window_bytes"] / max(st["n_verified"], 1) > 2048  # and windows outgrow the LDS ring
+        assert_same_hits(b.download(), want)
+        assert len(want) >= len(reads) - 2
+        b.close()
+
+
+def test_tiny_index_of_the_reference_unit_test():
+    """the literal 10-symbol database of index.rs:860-873: fewer rows than one rank block"""
+    ix = M.MGIndex.build([(1, 10, b"ACGT"), (1, 11, b"TTAA"), (2, 20, b"GG")], occ_k=8, sa_s=8, threads=1)
+    orc = O.Index.build([(1, 10, b"ACGT"), (1, 11, b"TTAA"), (2, 20, b"GG")], 8, 8)
+    reads = [b"ACGT", b"TTAA", b"GG", b"ACGTTTAAGG", b"CGTTTA", b"TTAAACGT", b"NNNN", b"A"]
+    bases, off = helpers.reads_to_batch(reads)
+    for flags in ALL_FLAGS:
+        ix.to_device(0, flags)
+        for over in (dict(seed_size=2, seed_interval=1, edit_rate=0.3), dict(seed_size=4, seed_interval=1, edit_rate=0.0),
+                     dict(seed_size=3, seed_interval=2, edit_rate=0.5, min_seed=1.0)):
+            mp, op = both_params(**over)
+            want, _ = orc.bin_batch(bases, off, op, threads=1)
+            assert_same_hits(ix.bin_batch(bases, off, mp, device=0), want)
 
 
 def test_committed_golden_result_lines(tricky):
