@@ -252,6 +252,25 @@ def test_long_reads_take_the_ssw_word_kernel_path(tricky, read_len):
         assert_same_hits(got, want)
 
 
+def test_repeated_calls_with_changing_batch_shapes(small_db):
+    """mtsv_bin_batch reuses / regrows its cached workspace: sizes going up and down, different read
+    lengths and parameter sets back to back, two devices-structure flavours, same answers"""
+    import random
+    ix, orc = small_db
+    rng = random.Random(77)
+    ix.to_device(0)
+    for it in range(12):
+        n = rng.choice([1, 7, 300, 2500, 40, 9000, 3])
+        L = rng.choice([36, 100, 150, 250, 301])
+        over = rng.choice([{}, dict(max_candidates=2), dict(seed_size=14, seed_interval=6), dict(edit_rate=0.05)])
+        if it == 6:
+            ix.to_device(0, M.DEV_SAMPLED_SA_ONLY)
+        bases, off = M.synth_reads(ix, seed=1000 + it, n_reads=n, read_len=L)
+        mp, op = both_params(**over)
+        want, _ = orc.bin_batch(bases, off, op, threads=8)
+        assert_same_hits(ix.bin_batch(bases, off, mp, device=0), want)
+
+
 def test_counters_equal_oracle_counters(small_db):
     """the device counts the same work the reference does (SURVEY 8(d) accounting)"""
     ix, orc = small_db
