@@ -79,10 +79,18 @@ def main():
 
     if not torch.cuda.is_available() or M.device_count() < 1:
         sys.exit("bench.py needs a HIP device: libmtsv_amd has no CPU path")
+    # rehearsal knob: several ranks sharing one GPU (gloo; NCCL refuses duplicate devices) to exercise
+    # the rank logic on a one-GPU box.  Never set by the driver.
+    shared_gpu = os.environ.get("MTSV_BENCH_SHARE_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if shared_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     def barrier():
         if world > 1:
@@ -148,7 +156,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
