@@ -113,6 +113,9 @@ int mtsv_index_build(uint64_t n_seqs, const uint32_t *tax_ids, const uint32_t *g
 /* mtsv-build: FASTA with `SEQID-TAXID` headers (src/util.rs:26-56, src/io.rs:135-150) */
 int mtsv_index_build_fasta(const char *fasta_path, uint32_t occ_k, uint64_t sa_s, int n_threads,
                            mtsv_index **out);
+/* Where later mtsv_index_build* / mtsv_synth_index calls run the suffix sort: a HIP device ordinal (prefix
+ * doubling in HBM, ~32 B per symbol) or -1 = host threads (default).  The index bytes are the same. */
+int mtsv_set_build_device(int hip_device);
 int mtsv_index_write(const mtsv_index *ix, const char *path);
 int mtsv_index_info(const mtsv_index *ix, mtsv_index_info_t *info);
 void mtsv_index_free(mtsv_index *ix);

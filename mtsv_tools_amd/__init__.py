@@ -17,6 +17,7 @@ from ._lib import (  # noqa: F401
     format_results,
     lib,
     lib_path,
+    set_build_device,
     synth_reads,
     version,
 )

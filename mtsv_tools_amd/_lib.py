@@ -56,7 +56,7 @@ HIT_DTYPE = np.dtype({"names": ["read", "tax_id", "gi", "edit", "strand", "offse
 EXPORTS = [
     "mtsv_last_error", "mtsv_version", "mtsv_params_default", "mtsv_device_count",
     "mtsv_index_load", "mtsv_index_build", "mtsv_index_build_fasta", "mtsv_index_write",
-    "mtsv_index_info", "mtsv_index_free", "mtsv_index_to_device", "mtsv_bin_batch",
+    "mtsv_index_info", "mtsv_index_free", "mtsv_set_build_device", "mtsv_index_to_device", "mtsv_bin_batch",
     "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run",
     "mtsv_batch_stats_get", "mtsv_batch_set_verify_mode", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads",
@@ -119,6 +119,12 @@ def version():
 
 def device_count():
     return lib().mtsv_device_count()
+
+
+def set_build_device(device):
+    """-1 = host suffix sort, >= 0 = GPU prefix doubling on that device (same index bytes)"""
+    lib().mtsv_set_build_device.argtypes = [C.c_int]
+    _check(lib().mtsv_set_build_device(device))
 
 
 def default_params(**over):

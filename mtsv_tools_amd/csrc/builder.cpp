@@ -13,6 +13,7 @@
 #include <fstream>
 #include <map>
 #include <stdexcept>
+#include <array>
 #include <thread>
 
 #include "mgindex.hpp"
@@ -144,8 +145,12 @@ struct SuffixSorter {
 
 }  // namespace
 
+// gpu_builder.hip
+void gpu_suffix_sort(const uint8_t* text, uint32_t n, uint64_t s, int device, std::vector<uint8_t>& bwt,
+                     std::vector<uint64_t>& sample, uint64_t* sentinel_row);
+
 void build_index(std::vector<SeqEntry> entries, uint32_t occ_k, uint64_t sa_s, int n_threads,
-                 HostIndex& ix) {
+                 HostIndex& ix, int gpu_device) {
     if (occ_k == 0 || sa_s == 0) throw std::runtime_error("arg: sampling intervals must be > 0");
     if (n_threads < 1) n_threads = 1;
     ix = HostIndex();
@@ -182,55 +187,86 @@ void build_index(std::vector<SeqEntry> entries, uint32_t occ_k, uint64_t sa_s, i
     ix.sentinel = '$';
     const uint64_t n = total + 1;
 
-    std::vector<uint32_t> sa;
-    SuffixSorter{ix.text.data(), n, n_threads}.sort(sa);
-
-    // bwt (index.rs:567)
-    ix.bwt.resize(n);
-    parallel_for(n, n_threads, [&](uint64_t lo, uint64_t hi, int) {
-        for (uint64_t i = lo; i < hi; i++) ix.bwt[i] = sa[i] ? ix.text[sa[i] - 1] : ix.text[n - 1];
-    });
-    // less (index.rs:570)
-    ix.less.assign(kLessLen, 0);
-    {
-        uint64_t hist[256] = {0};
-        for (uint64_t i = 0; i < n; i++) hist[ix.bwt[i]]++;
-        uint64_t cum = 0;
-        for (uint64_t c = 0; c < kLessLen; c++) {
-            ix.less[c] = cum;
-            cum += hist[c];
-        }
+    ix.s = sa_s;
+    uint64_t sentinel_row = 0;
+    if (gpu_device >= 0) {
+        // suffix array, BWT and samples on the GPU (gpu_builder.hip); only bwt + samples come back
+        gpu_suffix_sort(ix.text.data(), (uint32_t)n, sa_s, gpu_device, ix.bwt, ix.sample, &sentinel_row);
+    } else {
+        std::vector<uint32_t> sa;
+        SuffixSorter{ix.text.data(), n, n_threads}.sort(sa);
+        // bwt (index.rs:567)
+        ix.bwt.resize(n);
+        parallel_for(n, n_threads, [&](uint64_t lo, uint64_t hi, int) {
+            for (uint64_t i = lo; i < hi; i++) ix.bwt[i] = sa[i] ? ix.text[sa[i] - 1] : ix.text[n - 1];
+        });
+        // sample (index.rs:574)
+        ix.sample.resize((n + sa_s - 1) / sa_s);
+        for (uint64_t i = 0, j = 0; i < n; i += sa_s, j++) ix.sample[j] = sa[i];
+        for (uint64_t i = 0; i < n; i++)
+            if (sa[i] == 0) {
+                sentinel_row = i;
+                break;
+            }
     }
-    // Occ::new (index.rs:571): checkpoint j holds the inclusive count in bwt[0..=j*k]
+    // a non-sampled row whose BWT symbol is the sentinel goes to extra_rows; it is the suffix at 0
+    if (sentinel_row % sa_s != 0) ix.extra_rows.push_back({sentinel_row, 0});
+
+    // less (index.rs:570) and Occ::new (index.rs:571): checkpoint j = inclusive counts in bwt[0..=j*k];
+    // two passes over thread ranges aligned to k
     ix.k = occ_k;
     ix.occ.assign(kOccOuter, {});
     const uint64_t nchk = (n - 1) / occ_k + 1;
     static const uint8_t alpha[11] = {'A', 'C', 'G', 'T', 'N', 'a', 'c', 'g', 't', 'n', '$'};
     for (uint8_t a : alpha) ix.occ[a].assign(nchk, 0);
+    const int T = n_threads;
+    const uint64_t chk_per = (nchk + T - 1) / T;  // checkpoints per thread; thread t owns rows (c0*k - k, c1*k - k] shifted below
+    std::vector<std::array<uint64_t, 256>> part(T);
+    auto row_lo = [&](int t) { uint64_t c0 = std::min(nchk, (uint64_t)t * chk_per); return c0 == 0 ? 0 : (c0 - 1) * occ_k + 1; };
+    auto row_hi = [&](int t) { uint64_t c1 = std::min(nchk, (uint64_t)(t + 1) * chk_per); return t == T - 1 ? n : (c1 == 0 ? 0 : std::min<uint64_t>(n, (c1 - 1) * occ_k + 1)); };
     {
-        uint64_t cur[256] = {0};
-        uint64_t j = 0;
-        for (uint64_t i = 0; i < n; i++) {
-            cur[ix.bwt[i]]++;
-            if (i % occ_k == 0) {
-                for (uint8_t a : {'A', 'C', 'G', 'T', 'N', '$'}) ix.occ[a][j] = cur[a];
-                j++;
-            }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; t++)
+            pool.emplace_back([&, t] {
+                std::array<uint64_t, 256> c{};
+                for (uint64_t i = row_lo(t); i < row_hi(t); i++) c[ix.bwt[i]]++;
+                part[t] = c;
+            });
+        for (auto& th : pool) th.join();
+    }
+    std::vector<std::array<uint64_t, 256>> base(T);
+    {
+        std::array<uint64_t, 256> acc{};
+        for (int t = 0; t < T; t++) {
+            base[t] = acc;
+            for (int c = 0; c < 256; c++) acc[c] += part[t][c];
+        }
+        uint64_t cum = 0;
+        ix.less.assign(kLessLen, 0);
+        for (uint64_t c = 0; c < kLessLen; c++) {
+            ix.less[c] = cum;
+            cum += acc[c];
         }
     }
-    // sample (index.rs:574)
-    ix.s = sa_s;
-    ix.sample.resize((n + sa_s - 1) / sa_s);
-    for (uint64_t i = 0, j = 0; i < n; i += sa_s, j++) ix.sample[j] = sa[i];
-    for (uint64_t i = 0; i < n; i++)
-        if (ix.bwt[i] == '$') {
-            if (i % sa_s != 0) ix.extra_rows.push_back({i, sa[i]});
-            break;
-        }
+    {
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; t++)
+            pool.emplace_back([&, t] {
+                std::array<uint64_t, 256> cur = base[t];
+                for (uint64_t i = row_lo(t); i < row_hi(t); i++) {
+                    cur[ix.bwt[i]]++;
+                    if (i % occ_k == 0) {
+                        uint64_t j = i / occ_k;
+                        for (uint8_t a : {'A', 'C', 'G', 'T', 'N', '$'}) ix.occ[a][j] = cur[a];
+                    }
+                }
+            });
+        for (auto& th : pool) th.join();
+    }
 }
 
 void build_index_from_fasta(const std::string& fasta, uint32_t occ_k, uint64_t sa_s, int n_threads,
-                            HostIndex& out) {
+                            HostIndex& out, int gpu_device) {
     std::ifstream in(fasta, std::ios::binary);
     if (!in) throw std::runtime_error("io: cannot open " + fasta);
     struct Rec {
@@ -269,7 +305,7 @@ void build_index_from_fasta(const std::string& fasta, uint32_t occ_k, uint64_t s
     }
     std::vector<SeqEntry> entries;
     for (auto& r : recs) entries.push_back(SeqEntry{r.tax, r.gi, (const uint8_t*)r.seq.data(), r.seq.size()});
-    build_index(std::move(entries), occ_k, sa_s, n_threads, out);
+    build_index(std::move(entries), occ_k, sa_s, n_threads, out, gpu_device);
 }
 
 }  // namespace mtsv

@@ -17,6 +17,7 @@
 using namespace mtsv;
 
 static thread_local std::string g_err;
+static int g_build_device = -1;  // mtsv_set_build_device
 
 static int fail(const std::exception& e) {
     g_err = e.what();
@@ -110,16 +111,21 @@ int mtsv_index_build(uint64_t n_seqs, const uint32_t* tax_ids, const uint32_t* g
         std::vector<SeqEntry> e(n_seqs);
         for (uint64_t i = 0; i < n_seqs; i++) e[i] = SeqEntry{tax_ids[i], gis[i], seqs[i], seq_lens[i]};
         auto ix = std::make_unique<mtsv_index>();
-        build_index(std::move(e), occ_k, sa_s, n_threads, ix->host);
+        build_index(std::move(e), occ_k, sa_s, n_threads, ix->host, g_build_device);
         *out = ix.release();
     })
+}
+
+int mtsv_set_build_device(int hip_device) {
+    g_build_device = hip_device;
+    return MTSV_OK;
 }
 
 int mtsv_index_build_fasta(const char* fasta_path, uint32_t occ_k, uint64_t sa_s, int n_threads, mtsv_index** out) {
     if (!fasta_path || !out) return fail_arg("null argument");
     GUARD({
         auto ix = std::make_unique<mtsv_index>();
-        build_index_from_fasta(fasta_path, occ_k, sa_s, n_threads, ix->host);
+        build_index_from_fasta(fasta_path, occ_k, sa_s, n_threads, ix->host, g_build_device);
         *out = ix.release();
     })
 }
@@ -366,7 +372,7 @@ int mtsv_synth_index(uint64_t seed, uint32_t n_taxa, uint32_t gis_per_taxon, uin
         std::vector<SeqEntry> e(nseq);
         for (uint64_t i = 0; i < nseq; i++) e[i] = SeqEntry{tax[i], gi[i], (const uint8_t*)seqs[i].data(), seqs[i].size()};
         auto ix = std::make_unique<mtsv_index>();
-        build_index(std::move(e), occ_k, sa_s, n_threads, ix->host);
+        build_index(std::move(e), occ_k, sa_s, n_threads, ix->host, g_build_device);
         *out = ix.release();
     })
 }

@@ -52,10 +52,11 @@ struct SeqEntry {
     uint64_t len;
 };
 // MGIndex::new (src/index.rs:491-582)
+// gpu_device >= 0: suffix array / BWT / samples are built on that HIP device (gpu_builder.hip)
 void build_index(std::vector<SeqEntry> entries, uint32_t occ_k, uint64_t sa_s, int n_threads,
-                 HostIndex& out);
+                 HostIndex& out, int gpu_device = -1);
 // parse_fasta_db (src/io.rs:135-150) + parse_read_header (src/util.rs:26-56) + build_index
 void build_index_from_fasta(const std::string& fasta, uint32_t occ_k, uint64_t sa_s, int n_threads,
-                            HostIndex& out);
+                            HostIndex& out, int gpu_device = -1);
 
 }  // namespace mtsv

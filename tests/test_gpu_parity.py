@@ -329,3 +329,25 @@ def test_full_size_properties(medium, tmp_path):
     ns = 4000
     want, _ = O.Index.read(p).bin_batch(bases[: ns * 150], off[: ns + 1], threads=8)
     assert_same_hits(whole[whole["read"] < ns], want)
+
+
+def test_gpu_index_builder_writes_the_same_bytes(tmp_path):
+    """mtsv_set_build_device: suffix array by prefix doubling on the GPU -> byte-identical MG-index"""
+    entries, _, _ = helpers.tricky_db(seed=13)
+    big = M.MGIndex.synth(seed=3, n_taxa=32, gis_per_taxon=4, seq_len=30000)  # host build, n ~ 3.8e6
+    a, b, c, d = (str(tmp_path / f"{x}.idx") for x in "abcd")
+    M.MGIndex.build(entries, 64, 32, threads=4).write(a)
+    big.write(c)
+    try:
+        M.set_build_device(0)
+        M.MGIndex.build(entries, 64, 32, threads=4).write(b)
+        M.MGIndex.synth(seed=3, n_taxa=32, gis_per_taxon=4, seq_len=30000).write(d)
+        for k, s in ((3, 5), (128, 7)):
+            e, f = str(tmp_path / "e.idx"), str(tmp_path / "f.idx")
+            M.MGIndex.build(entries, k, s, threads=2).write(e)
+            O.Index.build(entries, k, s).write(f)
+            assert open(e, "rb").read() == open(f, "rb").read()
+    finally:
+        M.set_build_device(-1)
+    assert open(a, "rb").read() == open(b, "rb").read()
+    assert open(c, "rb").read() == open(d, "rb").read()
