@@ -117,7 +117,11 @@ def main():
         except OSError:
             pass
         if not index_cached:
-            ixb = M.MGIndex.synth(SEED_DB, n_taxa, gis, seq_len, threads=min(32, ncpu))  # host-side, untimed
+            # untimed setup: suffix array by prefix doubling on this rank's GPU (MTSV_BENCH_HOST_BUILD=1: host threads)
+            if os.environ.get("MTSV_BENCH_HOST_BUILD") != "1":
+                M.set_build_device(local_rank)
+            ixb = M.MGIndex.synth(SEED_DB, n_taxa, gis, seq_len, threads=min(32, ncpu))
+            M.set_build_device(-1)
             ixb.write(idx_path + ".tmp")
             ixb.close()
             os.replace(idx_path + ".tmp", idx_path)
