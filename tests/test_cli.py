@@ -122,3 +122,44 @@ def test_chunk_mode_binner_then_collapse_equals_oracle_per_chunk(tmp_path):
         assert subprocess.run([collapse, "-o", str(a), "--mode", mode, *gpu_files]).returncode == 0
         assert subprocess.run([collapse, "-o", str(b), "--mode", mode, *cpu_files]).returncode == 0
         assert a.read_text() == b.read_text() and len(a.read_text()) > 200
+
+
+def test_mtsv_build_cli_writes_the_reference_layout(tmp_path):
+    """bin/mtsv-build (host suffix sort here: --device -1): same bytes as the library builder and the
+    oracle's MGIndex::new restatement; header grammar and mapping-file handling of src/io.rs"""
+    import helpers
+    from oracle import oracle as O
+
+    build = os.path.join(ROOT, "mtsv_tools_amd", "bin", "mtsv-build")
+    entries, _, _ = helpers.tricky_db(seed=4)
+    fa = tmp_path / "db.fasta"
+    with open(fa, "w") as f:
+        for tax, gi, seq in entries:
+            f.write(f">{gi}-{tax} desc\n{seq.decode()}\n")
+    out, ref = tmp_path / "cli.idx", tmp_path / "orc.idx"
+    r = subprocess.run([build, "-f", str(fa), "-i", str(out), "--device", "-1", "--sa-sample", "16", "--sample-interval", "32"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    O.Index.build(entries, 32, 16).write(str(ref))
+    assert open(out, "rb").read() == open(ref, "rb").read()
+    # mapping file: header, taxid, seqid columns (any of , tab ; | or whitespace), --skip-missing
+    fa2 = tmp_path / "db2.fasta"
+    with open(fa2, "w") as f:
+        for i, (tax, gi, seq) in enumerate(entries):
+            f.write(f">seq{i} x\n{seq.decode()}\n")
+        f.write(">unmapped\nACGTACGTACGTACGTACGT\n")
+    mp = tmp_path / "map.tsv"
+    with open(mp, "w") as f:
+        f.write("Header\tTaxID\tSeqID\n")
+        for i, (tax, gi, seq) in enumerate(entries):
+            f.write(f"seq{i}\t{tax}\t{gi}\n")
+    out2 = tmp_path / "cli2.idx"
+    r = subprocess.run([build, "-f", str(fa2), "-i", str(out2), "--device", "-1", "--sa-sample", "16", "--sample-interval", "32",
+                        "--mapping", str(mp)], capture_output=True, text=True)
+    assert r.returncode == 1  # missing mapping for a header
+    r = subprocess.run([build, "-f", str(fa2), "-i", str(out2), "--device", "-1", "--sa-sample", "16", "--sample-interval", "32",
+                        "--mapping", str(mp), "--skip-missing"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert open(out2, "rb").read() == open(ref, "rb").read()
+    assert subprocess.run([build, "-f", str(fa), "-i", str(out), "--sa-sample", "x"], capture_output=True).returncode == 101
+    assert subprocess.run([build, "-f", str(tmp_path / "nope.fa"), "-i", str(out), "--device", "-1"], capture_output=True).returncode == 101
