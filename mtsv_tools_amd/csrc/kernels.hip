@@ -686,19 +686,21 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
                     key = (lower == up) ? min(key, other) : max(key, other);
                 }
             uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-            uint32_t b = 0, ws = 0, we = 0;
+            uint32_t b = 0, ws = 0, we = 0, btax = 0;
             bool ok = false;
             if (gl < gnh) {
                 b = min(find_bin(ix, site), ix.n_bins - 1);
                 DevBin bin = ix.bins[b];
+                btax = bin.tax_id;  // travels with the walk: no dependent reload of the candidate's bin
                 ok = candidate_window(site, q, bin, gg.L, gg.ED, &ws, &we);
             }
             Walk w{false, 0, 0, 0, 0};
-            uint32_t gnc = 0, ms = 0, me = 0, mb = 0, mn = 0;
+            uint32_t wtax = 0;
+            uint32_t gnc = 0, ms = 0, me = 0, mb = 0, mn = 0, mtax = 0;
             for (uint32_t i = 0; i < maxnh; i++) {
                 const int src = (int)(gbase + i);
                 uint32_t wsi = (uint32_t)__shfl((int)ws, src), wei = (uint32_t)__shfl((int)we, src);
-                uint32_t bi = (uint32_t)__shfl((int)b, src);
+                uint32_t bi = (uint32_t)__shfl((int)b, src), ti = (uint32_t)__shfl((int)btax, src);
                 bool oki = __shfl((int)ok, src) != 0;
                 if (i < gnh) {
                     bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
@@ -708,23 +710,24 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_
                         w.n++;
                     } else {
                         if (w.have && w.n >= gg.min_seeds) {
-                            if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
+                            if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
                             gnc++;
                         }
                         w.have = oki;
                         w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
+                        wtax = ti;
                     }
                 }
             }
             if (w.have && w.n >= gg.min_seeds) {
-                if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
+                if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
                 gnc++;
             }
             uint32_t maxnc = gnc;
             maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 16));
             maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 32));
             maxnc = __builtin_amdgcn_readfirstlane(maxnc);
-            const uint32_t tax = gl < gnc ? ix.bins[mb].tax_id : 0;
+            const uint32_t tax = gl < gnc ? mtax : 0;
             uint32_t rank = 0;
             for (uint32_t j = 0; j < maxnc; j++) {
                 uint32_t nj = (uint32_t)__shfl((int)mn, (int)(gbase + j));
