@@ -150,6 +150,12 @@ int mtsv_batch_set_verify_mode(mtsv_batch *b, int mode);
 int mtsv_batch_upload(mtsv_batch *b, const uint8_t *bases, const uint64_t *read_off,
                       uint64_t n_reads);
 int mtsv_batch_run(mtsv_batch *b, const mtsv_params *params); /* synchronous: returns when done */
+/* upload + run in one call for host buffers of any size: the reads are cut into slices of at most
+ * the workspace's max_reads / max_bases, and slice k+1 is copied to the device while slice k runs
+ * (two input buffers, a copy stream), so the PCIe transfer hides behind the kernels.  Hit `read`
+ * fields index the whole host batch.  Stats cover all slices. */
+int mtsv_batch_run_host(mtsv_batch *b, const uint8_t *bases, const uint64_t *read_off,
+                        uint64_t n_reads, const mtsv_params *params);
 int mtsv_batch_stats_get(const mtsv_batch *b, mtsv_batch_stats *st);
 int mtsv_batch_download(mtsv_batch *b, mtsv_hit **hits, uint64_t *n_hits);
 void mtsv_batch_free(mtsv_batch *b);

@@ -57,7 +57,7 @@ EXPORTS = [
     "mtsv_last_error", "mtsv_version", "mtsv_params_default", "mtsv_device_count",
     "mtsv_index_load", "mtsv_index_build", "mtsv_index_build_fasta", "mtsv_index_write",
     "mtsv_index_info", "mtsv_index_free", "mtsv_set_build_device", "mtsv_index_to_device", "mtsv_bin_batch",
-    "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run",
+    "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run", "mtsv_batch_run_host",
     "mtsv_batch_stats_get", "mtsv_batch_set_verify_mode", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads",
 ]
@@ -93,6 +93,7 @@ def lib():
         L.mtsv_batch_create.argtypes = [vp, i32, u64, u64, u64, C.POINTER(vp)]
         L.mtsv_batch_upload.argtypes = [vp, vp, vp, u64]
         L.mtsv_batch_run.argtypes = [vp, C.POINTER(Params)]
+        L.mtsv_batch_run_host.argtypes = [vp, vp, vp, u64, C.POINTER(Params)]
         L.mtsv_batch_set_verify_mode.argtypes = [vp, i32]
         L.mtsv_batch_stats_get.argtypes = [vp, C.POINTER(BatchStats)]
         L.mtsv_batch_download.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
@@ -139,7 +140,8 @@ def _hits_from(ptr, n):
     try:
         if n == 0:
             return np.zeros(0, dtype=HIT_DTYPE)
-        return np.frombuffer(C.string_at(ptr.value, n * HIT_DTYPE.itemsize), dtype=HIT_DTYPE).copy()
+        raw = (C.c_ubyte * (n * HIT_DTYPE.itemsize)).from_address(ptr.value)
+        return np.frombuffer(raw, dtype=HIT_DTYPE).copy()   # one copy, then the C array is freed
     finally:
         lib().mtsv_hits_free(ptr)
 
@@ -237,6 +239,14 @@ class Batch:
     def run(self, params=None):
         params = params or default_params()
         _check(lib().mtsv_batch_run(self.h, C.byref(params)))
+
+    def run_host(self, bases, read_off, params=None):
+        """mtsv_batch_run_host: host buffers of any size, sliced and double-buffered on the device."""
+        params = params or default_params()
+        bases = np.ascontiguousarray(bases, dtype=np.uint8)
+        read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+        _check(lib().mtsv_batch_run_host(self.h, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
+                                         C.byref(params)))
 
     def stats(self):
         s = BatchStats()

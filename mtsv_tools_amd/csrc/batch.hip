@@ -2,7 +2,13 @@
 // path.  Replaces the producer -> workers -> joiner queue of vendor/cue/src/lib.rs:45-105 with
 // large HBM-resident batches: reads stay on the device between stages, every stage is one launch
 // over the whole batch, and the only host round-trips are two 8-byte totals per pass.
+#include <chrono>
 #include <cmath>
+#include <condition_variable>
+#include <exception>
+#include <mutex>
+#include <thread>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <stdexcept>
@@ -15,6 +21,24 @@
 namespace mtsv {
 
 namespace {
+// memcpy / first-touch split over a few threads for large host buffers
+template <class F>
+void parallel_ranges(uint64_t n, F f) {
+    const int nt = n >= (64ull << 20) ? 4 : n >= (8ull << 20) ? 2 : 1;
+    if (nt == 1) return f(0, n);
+    std::vector<std::thread> th;
+    const uint64_t chunk = ((n + nt - 1) / nt + 4095) & ~4095ull;
+    for (int k = 0; k < nt; k++) {
+        uint64_t a = std::min(n, chunk * k), b = std::min(n, chunk * (k + 1));
+        if (a < b) th.emplace_back([=] { f(a, b); });
+    }
+    for (auto& t : th) t.join();
+}
+double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+void parallel_copy(uint8_t* dst, const uint8_t* src, uint64_t n) {
+    parallel_ranges(n, [=](uint64_t a, uint64_t b) { memcpy(dst + a, src + a, b - a); });
+}
+
 template <class T>
 void dev_alloc(T** p, uint64_t count, uint64_t* bytes) {
     uint64_t b = std::max<uint64_t>(count, 1) * sizeof(T);
@@ -71,6 +95,13 @@ Batch::~Batch() {
                     (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand, (void*)d_out,
                     (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_heavy_list})
         (void)hipFree(p);
+    (void)hipFree(d_bases2);
+    for (int b = 0; b < 2; b++) {
+        if (h_stage_bases[b]) (void)hipHostFree(h_stage_bases[b]);
+        if (h_stage_off[b]) (void)hipHostFree(h_stage_off[b]);
+    }
+    (void)hipFree(d_read_off2);
+    if (copy_stream) (void)hipStreamDestroy(copy_stream);
     (void)hipHostFree(h_counters);
     for (auto& e : ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(stream);
@@ -99,29 +130,54 @@ void Batch::upload(const uint8_t* bases, const uint64_t* read_off, uint64_t n) {
 
 // counters in d_counters: [0] scan total (u64), [1] wl_count (u32), [2] lf_steps, [3] n_cand,
 // [4] n_verified, [5] window_bytes, [6] second scan total
-void Batch::run(const mtsv_params& p) {
+void Batch::begin_run(const mtsv_params& p) {
     if (!(p.edit_rate >= 0.0 && p.edit_rate <= 1.0)) throw std::runtime_error("arg: edit_rate must be within [0, 1]");
     if (!(p.min_seed >= 0.0) || !std::isfinite(p.min_seed)) throw std::runtime_error("arg: min_seed must be finite and >= 0");
     if (p.seed_size == 0 || p.seed_interval == 0) throw std::runtime_error("arg: seed_size and seed_interval must be > 0");
-    if (max_len > kMaxReadLen)
-        throw std::runtime_error("limit: read of " + std::to_string(max_len) + " bases; this build verifies reads up to " +
-                                 std::to_string(kMaxReadLen));
     HIP_CHECK(hipSetDevice(di->device));
+    memset(&stats, 0, sizeof stats);
+    memset(stage_acc, 0, sizeof stage_acc);
+    n_hits_total = 0;
+    HIP_CHECK(hipMemsetAsync(d_counters, 0, 8 * sizeof(uint64_t), stream));
+    HIP_CHECK(hipEventRecord(ev[8], stream));
+}
+
+void Batch::end_run() {
+    HIP_CHECK(hipEventRecord(ev[9], stream));
+    HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipStreamSynchronize(stream));
+    HIP_CHECK(hipEventElapsedTime(&stage_acc[7], ev[8], ev[9]));
+    for (int s = 0; s < MTSV_N_STAGES; s++) stats.stage_ms[s] = stage_acc[s];
+    stats.n_reads = n_reads;
+    stats.lf_steps = h_counters[2];
+    stats.n_candidates = h_counters[3];
+    stats.n_verified = h_counters[4];
+    stats.window_bytes = h_counters[5];
+    stats.n_hits = n_hits_total;
+}
+
+void Batch::run(const mtsv_params& p) {
+    begin_run(p);
+    run_slice(p, d_bases, d_read_off, n_reads, max_len, 0);
+    end_run();
+}
+
+// One slice of reads already in HBM (bases `sb`, offsets `so`, `n_slice` reads whose first read is
+// number `read_base` of the caller's batch): passes over the slice, hits appended to d_hits.
+void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n_slice, uint32_t slice_max_len,
+                      uint64_t read_base) {
+    if (slice_max_len > kMaxReadLen)
+        throw std::runtime_error("limit: read of " + std::to_string(slice_max_len) + " bases; this build verifies reads up to " +
+                                 std::to_string(kMaxReadLen));
     const DevIndexView& v = di->view;
     const uint32_t K = p.seed_size, G = p.seed_interval;
-    const uint32_t max_ns = max_len >= K ? (max_len - K) / G + 1 : 0;
-    memset(&stats, 0, sizeof stats);
-    stats.n_reads = n_reads;
-    n_hits_total = 0;
-    float stage_ms[MTSV_N_STAGES] = {0};
-    HIP_CHECK(hipMemsetAsync(d_counters, 0, 8 * sizeof(uint64_t), stream));
+    const uint32_t max_ns = slice_max_len >= K ? (slice_max_len - K) / G + 1 : 0;
+    float* stage_ms = stage_acc;
 
-    uint64_t pass_reads = n_reads;
+    uint64_t pass_reads = n_slice;
     uint64_t r0 = 0;
-    hipEvent_t t_begin = ev[8], t_end = ev[9];
-    HIP_CHECK(hipEventRecord(t_begin, stream));
-    while (r0 < n_reads) {
-        const uint32_t nr = (uint32_t)std::min<uint64_t>(pass_reads, n_reads - r0);
+    while (r0 < n_slice) {
+        const uint32_t nr = (uint32_t)std::min<uint64_t>(pass_reads, n_slice - r0);
         const uint32_t nstr = nr * 2;
         const uint64_t slots = (uint64_t)nstr * max_ns;
         if (slots > seed_cap) {
@@ -137,10 +193,10 @@ void Batch::run(const mtsv_params& p) {
         }
         // ---- seeds ----
         HIP_CHECK(hipEventRecord(ev[0], stream));
-        launch_search(stream, v, d_bases, d_read_off, (uint32_t)r0, nr, max_ns, K, G, d_seed_lo, d_seed_cnt);
+        launch_search(stream, v, sb, so, (uint32_t)r0, nr, max_ns, K, G, d_seed_lo, d_seed_cnt);
         HIP_CHECK(hipEventRecord(ev[1], stream));
         if (max_ns)
-            launch_thin(stream, d_read_off, (uint32_t)r0, nr, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
+            launch_thin(stream, so, (uint32_t)r0, nr, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
                         d_seed_pre, d_strand_hits, d_strand_nseeds);
         else {
             HIP_CHECK(hipMemsetAsync(d_strand_hits, 0, (uint64_t)nstr * 4, stream));
@@ -173,7 +229,7 @@ void Batch::run(const mtsv_params& p) {
         // counters: [1] lo = round-0 worklist count, [7] lo/hi = ping-pong counts of later rounds
         HIP_CHECK(hipMemsetAsync(d_counters + 1, 0, 8, stream));
         HIP_CHECK(hipMemsetAsync(d_counters + 7, 0, 8, stream));
-        launch_coalesce(stream, v, d_read_off, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, p.max_candidates, d_strand_off,
+        launch_coalesce(stream, v, so, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, p.max_candidates, d_strand_off,
                         d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next, d_cand_rs,
                         d_cand_status, d_strand_ncand, d_worklist, (uint32_t*)(d_counters + 1), d_heavy_list,
                         (uint32_t*)(d_counters + 1) + 1, (unsigned long long*)(d_counters + 3));
@@ -181,8 +237,8 @@ void Batch::run(const mtsv_params& p) {
         // ---- verify: rounds over the same-TaxId chains ----
         {
             EvalArgs a;
-            a.bases = d_bases;
-            a.read_off = d_read_off;
+            a.bases = sb;
+            a.read_off = so;
             a.r0 = (uint32_t)r0;
             a.edit_rate = p.edit_rate;
             a.max_candidates = p.max_candidates;
@@ -198,10 +254,10 @@ void Batch::run(const mtsv_params& p) {
             a.worklist = d_worklist;
             a.wl_count = (const uint32_t*)(d_counters + 1);
             a.wl_cursor = (uint32_t*)(d_counters + 7);
-            if (verify_mode == 1 && max_len <= 253)
-                launch_edit_myers(stream, v, a, total_hits, max_len);
+            if (verify_mode == 1 && slice_max_len <= 253)
+                launch_edit_myers(stream, v, a, total_hits, slice_max_len);
             else
-                launch_evaluate(stream, v, a, total_hits, max_len);
+                launch_evaluate(stream, v, a, total_hits, slice_max_len);
             stats.n_rounds = 1;
             launch_resolve(stream, nstr, p.max_candidates, p.max_assignments, d_strand_off, d_strand_ncand, d_cand_status,
                            d_out, d_strand_nout);
@@ -224,7 +280,7 @@ void Batch::run(const mtsv_params& p) {
             d_hits = nh;
             hits_cap = ncap;
         }
-        launch_gather(stream, nstr, (uint32_t)r0, d_strand_off, d_strand_nout, d_out_off, d_out, d_hits, n_hits_total);
+        launch_gather(stream, nstr, read_base + r0, d_strand_off, d_strand_nout, d_out_off, d_out, d_hits, n_hits_total);
         HIP_CHECK(hipEventRecord(ev[7], stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         HIP_CHECK(hipGetLastError());
@@ -236,16 +292,132 @@ void Batch::run(const mtsv_params& p) {
         }
         r0 += nr;
     }
-    HIP_CHECK(hipEventRecord(t_end, stream));
-    HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-    HIP_CHECK(hipStreamSynchronize(stream));
-    HIP_CHECK(hipEventElapsedTime(&stage_ms[7], t_begin, t_end));
-    for (int s = 0; s < MTSV_N_STAGES; s++) stats.stage_ms[s] = stage_ms[s];
-    stats.lf_steps = h_counters[2];
-    stats.n_candidates = h_counters[3];
-    stats.n_verified = h_counters[4];
-    stats.window_bytes = h_counters[5];
-    stats.n_hits = n_hits_total;
+}
+
+// Host buffers in, hits resident on the device out: the batch is cut into slices of at most
+// max_reads reads / max_bases bases; an uploader thread copies slice k+1 into the second input
+// buffer on its own stream while the kernels of slice k run, so PCIe time hides behind compute
+// (pageable host memory makes hipMemcpyAsync block its caller, hence the thread).
+void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p) {
+    HIP_CHECK(hipSetDevice(di->device));
+    if (!d_bases2) {
+        dev_alloc(&d_bases2, max_bases + 64, &bytes);
+        dev_alloc(&d_read_off2, max_reads + 1, &bytes);
+        HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
+        // pinned staging: a copy from pageable memory runs at ~5-20 GB/s on this platform, from pinned
+        // memory at ~57 GB/s (tools/pcie_rates.hip), and a host memcpy into it at >20 GB/s per thread
+        for (int b = 0; b < 2; b++) {
+            HIP_CHECK(hipHostMalloc((void**)&h_stage_bases[b], max_bases + 64));
+            HIP_CHECK(hipHostMalloc((void**)&h_stage_off[b], (max_reads + 1) * sizeof(uint32_t)));
+        }
+    }
+    const bool trace = getenv("MTSV_TRACE") != nullptr;
+    struct Slice {
+        uint64_t begin, end;
+        uint32_t max_len;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<Slice> ready;
+    uint64_t consumed = 0;
+    bool upload_done = false, abort = false;
+    std::exception_ptr upload_err;
+    uint8_t* const buf_b[2] = {d_bases, d_bases2};
+    uint32_t* const buf_o[2] = {d_read_off, d_read_off2};
+
+    std::thread uploader([&] {
+        try {
+            HIP_CHECK(hipSetDevice(di->device));
+            uint64_t s = 0, k = 0;
+            while (s < n) {
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return abort || k < consumed + 2; });
+                    if (abort) break;
+                }
+                uint64_t e = std::min(n, s + max_reads);
+                if (read_off[e] < read_off[s]) throw std::runtime_error("arg: read_off is not ascending");
+                if (read_off[e] - read_off[s] > max_bases) {  // largest e with at most max_bases bases
+                    uint64_t lo = s, hi = e;
+                    while (lo < hi) {
+                        uint64_t mid = (lo + hi + 1) / 2;
+                        if (read_off[mid] >= read_off[s] && read_off[mid] - read_off[s] <= max_bases) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    e = lo;
+                    if (e == s) throw std::runtime_error("limit: one read holds more bases than the batch workspace");
+                }
+                const uint64_t cnt = e - s, first = read_off[s], nb = read_off[e] - first;
+                uint32_t* off32 = h_stage_off[k & 1];
+                uint32_t ml = 0;
+                for (uint64_t i = 0; i <= cnt; i++) {
+                    if (i && read_off[s + i] < read_off[s + i - 1]) throw std::runtime_error("arg: read_off is not ascending");
+                    off32[i] = (uint32_t)(read_off[s + i] - first);
+                    if (i) ml = std::max(ml, off32[i] - off32[i - 1]);
+                }
+                const double t0 = now_s();
+                if (nb) {
+                    parallel_copy(h_stage_bases[k & 1], bases + first, nb);
+                    HIP_CHECK(hipMemcpyAsync(buf_b[k & 1], h_stage_bases[k & 1], nb, hipMemcpyHostToDevice, copy_stream));
+                }
+                HIP_CHECK(hipMemcpyAsync(buf_o[k & 1], off32, (cnt + 1) * 4, hipMemcpyHostToDevice, copy_stream));
+                const double t1 = now_s();
+                HIP_CHECK(hipStreamSynchronize(copy_stream));
+                if (trace) fprintf(stderr, "[run_host] slice %llu: stage %.1f ms, h2d %.1f ms (%.1f MB)\n", (unsigned long long)k, (t1 - t0) * 1e3, (now_s() - t1) * 1e3, nb / 1e6);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    ready.push_back(Slice{s, e, ml});
+                }
+                cv.notify_all();
+                s = e;
+                k++;
+            }
+        } catch (...) {
+            std::lock_guard<std::mutex> lk(mu);
+            upload_err = std::current_exception();
+        }
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            upload_done = true;
+        }
+        cv.notify_all();
+    });
+
+    std::exception_ptr err;
+    try {
+        n_reads = n;
+        max_len = 0;
+        begin_run(p);
+        for (uint64_t k = 0;; k++) {
+            Slice sl;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return ready.size() > k || upload_done; });
+                if (upload_err) std::rethrow_exception(upload_err);
+                if (ready.size() <= k) break;
+                sl = ready[k];
+            }
+            max_len = std::max(max_len, sl.max_len);
+            const double t0 = now_s();
+            run_slice(p, buf_b[k & 1], buf_o[k & 1], sl.end - sl.begin, sl.max_len, sl.begin);
+            if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                consumed = k + 1;
+            }
+            cv.notify_all();
+        }
+        end_run();
+    } catch (...) {
+        err = std::current_exception();
+    }
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        abort = true;
+    }
+    cv.notify_all();
+    uploader.join();
+    if (err) std::rethrow_exception(err);
 }
 
 void Batch::download(mtsv_hit** hits, uint64_t* n) {
@@ -253,6 +425,12 @@ void Batch::download(mtsv_hit** hits, uint64_t* n) {
     mtsv_hit* h = (mtsv_hit*)malloc(std::max<uint64_t>(n_hits_total, 1) * sizeof(mtsv_hit));
     if (!h) throw std::runtime_error("nomem: result array");
     if (n_hits_total) {
+        // fault the fresh pages in from several threads: a D2H copy into untouched malloc memory is
+        // page-fault bound (~12 GB/s instead of ~55)
+        uint8_t* hb = (uint8_t*)h;
+        parallel_ranges(n_hits_total * sizeof(mtsv_hit), [=](uint64_t a, uint64_t b) {
+            for (uint64_t o = a; o < b; o += 4096) hb[o] = 0;
+        });
         hipError_t e = hipMemcpy(h, d_hits, n_hits_total * sizeof(mtsv_hit), hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
             free(h);

@@ -11,12 +11,12 @@ namespace mtsv {
 struct Batch {
     mtsv_index* ix;
     DeviceIndex* di;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr;
     uint64_t max_reads, max_bases, hit_cap, hits_cap = 0;
     uint64_t bytes = 0;
 
-    uint8_t* d_bases = nullptr;
-    uint32_t* d_read_off = nullptr;
+    uint8_t *d_bases = nullptr, *d_bases2 = nullptr;  // second input buffer: run_host() double-buffers slices
+    uint32_t *d_read_off = nullptr, *d_read_off2 = nullptr;
     uint32_t *d_seed_lo = nullptr, *d_seed_cnt = nullptr, *d_seed_pre = nullptr;
     uint64_t seed_cap = 0;
     uint32_t *d_strand_hits = nullptr, *d_strand_nseeds = nullptr, *d_strand_off = nullptr, *d_strand_ncand = nullptr,
@@ -29,6 +29,8 @@ struct Batch {
     uint32_t *d_cand_next = nullptr, *d_cand_rs = nullptr, *d_cand_status = nullptr, *d_heavy_list = nullptr;
     DevHit* d_hits = nullptr;
     uint64_t* h_counters = nullptr;  // pinned
+    uint8_t* h_stage_bases[2] = {nullptr, nullptr};  // pinned staging of run_host()
+    uint32_t* h_stage_off[2] = {nullptr, nullptr};
     hipEvent_t ev[10];
 
     std::vector<uint32_t> h_read_off;
@@ -37,6 +39,7 @@ struct Batch {
     uint64_t n_reads = 0;
     uint64_t n_hits_total = 0;
     mtsv_batch_stats stats{};
+    float stage_acc[MTSV_N_STAGES] = {0};
 
     Batch(mtsv_index* ix, DeviceIndex* di, uint64_t max_reads, uint64_t max_bases, uint64_t hit_cap);
     ~Batch();
@@ -45,7 +48,14 @@ struct Batch {
 
     void upload(const uint8_t* bases, const uint64_t* read_off, uint64_t n);
     void run(const mtsv_params& p);
+    void run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p);
     void download(mtsv_hit** hits, uint64_t* n);
+
+   private:
+    void begin_run(const mtsv_params& p);
+    void run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n_slice, uint32_t slice_max_len,
+                   uint64_t read_base);
+    void end_run();
 };
 
 }  // namespace mtsv

@@ -198,6 +198,12 @@ int mtsv_batch_run(mtsv_batch* b, const mtsv_params* params) {
     GUARD(b->impl.run(*params))
 }
 
+int mtsv_batch_run_host(mtsv_batch* b, const uint8_t* bases, const uint64_t* read_off, uint64_t n_reads,
+                        const mtsv_params* params) {
+    if (!b || !read_off || !params || (!bases && n_reads && read_off[n_reads] > read_off[0])) return fail_arg("null argument");
+    GUARD(b->impl.run_host(bases, read_off, n_reads, *params))
+}
+
 int mtsv_batch_stats_get(const mtsv_batch* b, mtsv_batch_stats* st) {
     if (!b || !st) return fail_arg("null argument");
     *st = b->impl.stats;
@@ -225,16 +231,20 @@ int mtsv_bin_batch(mtsv_index* ix, int hip_device, const uint8_t* bases, const u
     if (rc != MTSV_OK) return rc;
     GUARD({
         std::lock_guard<std::mutex> lk(ix->mu);
+        // Workspace for slices of <= 1 Mi reads: larger host batches stream through it (run_host),
+        // which bounds the workspace (~2.7 KB of HBM per read) and overlaps the copy with compute.
         const uint64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
+        const uint64_t slice_reads = std::min<uint64_t>(std::max<uint64_t>(n_reads, 1024), 1ull << 20);
+        const uint64_t slice_bases = n_reads > slice_reads
+                                         ? std::max<uint64_t>(1 << 16, (uint64_t)((double)nb / (double)n_reads * (double)slice_reads * 1.25) + 4096)
+                                         : std::max<uint64_t>(nb, 1 << 16);
         mtsv_batch*& cb = ix->cached_batch[hip_device];
-        if (!cb || cb->impl.max_reads < n_reads || cb->impl.max_bases < nb) {
+        if (!cb || cb->impl.max_reads < slice_reads || cb->impl.max_bases < slice_bases) {
             delete cb;
             cb = nullptr;
-            cb = new mtsv_batch(ix, device_index(ix, hip_device), std::max<uint64_t>(n_reads, 1024),
-                                std::max<uint64_t>(nb, 1 << 16), 0);
+            cb = new mtsv_batch(ix, device_index(ix, hip_device), slice_reads, slice_bases, 0);
         }
-        cb->impl.upload(bases, read_off, n_reads);
-        cb->impl.run(*params);
+        cb->impl.run_host(bases, read_off, n_reads, *params);
         cb->impl.download(hits, n_hits);
     })
 }

@@ -1418,7 +1418,7 @@ __global__ __launch_bounds__(256) void k_resolve(uint32_t n_strands, int64_t max
 // ---------------------------------------------------------------------------------------------
 // K5: gather per-strand hits into the final (read, strand, rank) order
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_gather(uint32_t n_strands, uint32_t r0, const uint32_t* __restrict__ strand_off,
+__global__ __launch_bounds__(256) void k_gather(uint32_t n_strands, uint64_t r0, const uint32_t* __restrict__ strand_off,
                                                 const uint32_t* __restrict__ strand_nout,
                                                 const uint32_t* __restrict__ out_off, const uint4* __restrict__ out,
                                                 DevHit* __restrict__ hits, uint64_t hits_base) {
@@ -1561,7 +1561,7 @@ void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, i
                        strand_off, strand_ncand, cand_status, out, strand_nout);
 }
 
-void launch_gather(hipStream_t s, uint32_t n_strands, uint32_t r0, const uint32_t* strand_off, const uint32_t* strand_nout,
+void launch_gather(hipStream_t s, uint32_t n_strands, uint64_t r0, const uint32_t* strand_off, const uint32_t* strand_nout,
                    const uint32_t* out_off, const uint4* out, DevHit* hits, uint64_t hits_base) {
     hipLaunchKernelGGL(k_gather, dim3(cdiv(n_strands, 256)), dim3(256), 0, s, n_strands, r0, strand_off, strand_nout,
                        out_off, out, hits, hits_base);

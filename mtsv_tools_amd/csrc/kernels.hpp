@@ -63,7 +63,7 @@ void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a,
 void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,
                     const uint32_t* strand_off, const uint32_t* strand_ncand, const uint32_t* cand_status, uint4* out,
                     uint32_t* strand_nout);
-void launch_gather(hipStream_t s, uint32_t n_strands, uint32_t r0, const uint32_t* strand_off, const uint32_t* strand_nout,
+void launch_gather(hipStream_t s, uint32_t n_strands, uint64_t r0, const uint32_t* strand_off, const uint32_t* strand_nout,
                    const uint32_t* out_off, const uint4* out, DevHit* hits, uint64_t hits_base);
 
 }  // namespace mtsv

@@ -201,6 +201,50 @@ def test_batch_split_when_hit_workspace_is_small(tricky):
     assert e.value.code == _lib.E_DEVICE
 
 
+def test_run_host_slices_match_oracle(tricky):
+    """mtsv_batch_run_host: a workspace much smaller than the batch -> many double-buffered slices,
+    cut by read count or by base count; hits (incl. the batch-wide read index) equal the oracle's."""
+    ix, orc, reads = tricky
+    mp, op = both_params()
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want, _ = orc.bin_batch(bases, off, op, threads=8)
+    for max_reads, max_bases in ((97, 1 << 16), (len(reads), 4096), (len(reads) + 5, len(bases) + 5)):
+        b = M.Batch(ix, 0, max_reads, max_bases)
+        b.run_host(bases, off, mp)
+        st = b.stats()
+        assert st["n_reads"] == len(reads)
+        if max_reads < len(reads) or max_bases < len(bases):
+            assert st["n_passes"] > 2
+        assert_same_hits(b.download(), want)
+        # the same workspace again, then an empty batch
+        b.run_host(bases, off, mp)
+        assert_same_hits(b.download(), want)
+        b.run_host(np.zeros(0, np.uint8), np.zeros(1, np.uint64), mp)
+        assert len(b.download()) == 0
+        b.close()
+
+
+def test_run_host_errors_surface_from_the_uploader(small_db):
+    ix, _ = small_db
+    ix.to_device(0)
+    b = M.Batch(ix, 0, 64, 1 << 16)
+    reads = [b"ACGT" * 30] * 200 + [b"ACGT" * 150] + [b"ACGT" * 30] * 50   # a 600-base read in slice 3
+    bases, off = helpers.reads_to_batch(reads)
+    with pytest.raises(M.MtsvError) as e:
+        b.run_host(bases, off)
+    assert e.value.code == _lib.E_LIMIT
+    bad = off.copy()
+    bad[150] = bad[149] - 1                                                # offsets not ascending
+    with pytest.raises(M.MtsvError) as e:
+        b.run_host(bases, bad)
+    assert e.value.code == _lib.E_ARG
+    # and the workspace is still usable afterwards
+    good, goff = helpers.reads_to_batch([b"ACGT" * 30] * 300)
+    b.run_host(good, goff)
+    b.close()
+
+
 def test_limits_and_argument_errors(small_db):
     ix, _ = small_db
     ix.to_device(0)
