@@ -2,7 +2,8 @@
 // libmtsv_amd: same flags and defaults (:26-113), same validation (:140-262), same exit codes
 // (0 ok, 2 query error, 3 no results path, 4 resume error, 11 write error, 12 read error;
 // invalid numbers abort like the reference's panics, exit 101), same results grammar
-// (src/binner.rs:310-379), same resume rule (:347-411).  Extras: --device, --batch-reads.
+// (src/binner.rs:310-379), same resume rule (:347-411).  Extras: --device, --batch-reads,
+// --parse-only (ingest check: prints record / base counts and checksums, needs no index or GPU).
 // The reads of a batch are processed on the GPU; result lines are written in input order (the
 // reference's order is unspecified: vendor/cue/src/lib.rs:67-74).
 #include <zlib.h>
@@ -10,6 +11,7 @@
 #include <cerrno>
 #include <condition_variable>
 #include <deque>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <thread>
@@ -22,6 +24,7 @@
 #include <vector>
 
 #include "../../include/mtsv_amd.h"
+#include "fastx_ingest.hpp"
 
 namespace {
 
@@ -216,7 +219,7 @@ struct Args {
     std::string fasta, fastq, index, results, output_format = "default";
     std::string threads = "4", edit = "0.13", seed_size = "18", seed_interval = "15", min_seed = "0.015",
                 max_hits = "2000", tune_max_hits = "200", max_assign, max_cand, read_offset = "0";
-    bool verbose = false, force = false;
+    bool verbose = false, force = false, parse_only = false;
     int device = 0;
     uint64_t batch_reads = 1u << 20;
 };
@@ -279,6 +282,7 @@ int main(int argc, char** argv) {
         else if (key == "-v") a.verbose = true;
         else if (key == "--device") a.device = atoi(val().c_str());
         else if (key == "--batch-reads") a.batch_reads = strtoull(val().c_str(), nullptr, 10);
+        else if (key == "--parse-only") a.parse_only = true;
         else if (key == "-h" || key == "--help") {
             printf("mtsv-binner (MI355X) -- flags as the reference: --fasta|--fastq, -i/--index, -m/--results, -t/--threads,\n"
                    "-e/--edit-rate, --seed-size, --seed-interval, --min-seed, --max-hits, --tune-max-hits, --max-assignments,\n"
@@ -293,14 +297,17 @@ int main(int argc, char** argv) {
     if (a.fasta.empty() == a.fastq.empty())
         usage_error(a.fasta.empty() ? "The following required arguments were not provided: --fasta <FASTA> | --fastq <FASTQ>"
                                     : "The argument '--fasta <FASTA>' cannot be used with '--fastq <FASTQ>'");
-    if (a.index.empty()) usage_error("The following required arguments were not provided: --index <INDEX>");
+    if (a.index.empty() && !a.parse_only) usage_error("The following required arguments were not provided: --index <INDEX>");
     if (a.output_format != "default" && a.output_format != "long")
         usage_error("'" + a.output_format + "' isn't a valid value for '--output-format <OUTPUT_FORMAT>'");
     g_verbose = a.verbose;
 
     const bool fastq = a.fasta.empty();
     const std::string input = fastq ? a.fastq : a.fasta;
-    (void)parse_usize(a.threads, "Invalid number entered for number of threads!");
+    const uint64_t t_flag = parse_usize(a.threads, "Invalid number entered for number of threads!");
+    // -t sized the reference's worker pool; here it sizes the host helper threads (parse, format)
+    unsigned host_threads = (unsigned)std::min<uint64_t>(std::max<uint64_t>(t_flag, 8), std::max(1u, std::thread::hardware_concurrency()));
+    if (const char* e = getenv("MTSV_HOST_THREADS")) host_threads = (unsigned)std::max(1, atoi(e));
     mtsv_params p;
     mtsv_params_default(&p);
     p.edit_rate = parse_f64(a.edit, "Invalid edit proportion entered!");
@@ -325,7 +332,7 @@ int main(int argc, char** argv) {
     p.seed_interval = (uint32_t)seed_gap;
     const bool long_fmt = a.output_format == "long";
 
-    if (a.results.empty()) {
+    if (a.results.empty() && !a.parse_only) {
         logmsg("ERROR", "No results path provided!");
         return 3;
     }
@@ -336,7 +343,7 @@ int main(int argc, char** argv) {
     uint64_t resume = 0;
     if (a.force) {
         logmsg("INFO", "Forcing overwrite of " + a.results);
-    } else if (exists) {
+    } else if (exists && !a.parse_only) {
         logmsg("INFO", "Existing results detected at " + a.results + "; resuming previous run.");
         if (resume_offset(a.results, input, fastq, &resume) != 0) {
             logmsg("ERROR", "Error computing resume offset");
@@ -347,12 +354,138 @@ int main(int argc, char** argv) {
     read_offset += resume;
 
     // get_fastx_and_write_matching_bin_ids (binner.rs:149-217)
+    // Producer: block-parallel ingest for plain files (fastx_ingest.hpp), the serial reader for gzip
+    // input and from the first irregular block on.  `emit` gets records in input order.
+    using mtsv_ingest::ReadBlock;
     FastxReader rd;
     rd.fastq = fastq;
     if (!rd.in.open(input)) {
         logmsg("ERROR", "Error running query: cannot open " + input);
         return 2;
     }
+    // batches are recycled (writer -> producer) so that steady state touches no fresh pages
+    struct BlockPool {
+        std::mutex mu;
+        std::vector<std::unique_ptr<ReadBlock>> free;
+        std::unique_ptr<ReadBlock> get() {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free.empty()) return std::make_unique<ReadBlock>();
+            auto b = std::move(free.back());
+            free.pop_back();
+            b->clear();
+            return b;
+        }
+        void put(std::unique_ptr<ReadBlock> b) {
+            std::lock_guard<std::mutex> lk(mu);
+            if (free.size() < 8) free.push_back(std::move(b));
+        }
+    } pool;
+    auto produce = [&](uint64_t batch_reads, const std::function<bool(std::unique_ptr<ReadBlock>)>& emit) -> bool {
+        auto w = pool.get();
+        uint64_t skipped = 0;
+        auto full = [&] { return w->n() >= batch_reads || w->bases.size() >= (1ull << 30); };
+        mtsv_ingest::ParallelFastx par;
+        bool serial_from_start = getenv("MTSV_SERIAL_INGEST") != nullptr || !par.open(input, fastq, host_threads, getenv("MTSV_INGEST_BLOCK") ? strtoull(getenv("MTSV_INGEST_BLOCK"), nullptr, 10) : (16ull << 20));
+        if (!serial_from_start) {
+            ReadBlock blk;
+            uint64_t irregular = 0;
+            for (;;) {
+                auto r = par.next(blk, &irregular);
+                if (r == mtsv_ingest::ParallelFastx::END) break;
+                if (r == mtsv_ingest::ParallelFastx::IRREGULAR) {
+                    logmsg("DEBUG", "input is not plain 4-line FASTQ / FASTA at byte " + std::to_string(irregular) + "; continuing with the serial reader");
+                    if (gzseek(rd.in.f, (z_off_t)irregular, SEEK_SET) < 0) {
+                        rd.fail("read error");
+                        return false;
+                    }
+                    serial_from_start = true;  // the serial loop below continues from here
+                    break;
+                }
+                uint64_t from = 0;
+                if (skipped < read_offset) {
+                    from = std::min<uint64_t>(read_offset - skipped, blk.n());
+                    skipped += from;
+                }
+                // cut the block at batch boundaries
+                while (from < blk.n()) {
+                    const uint64_t room = batch_reads > w->n() ? batch_reads - w->n() : 0;
+                    const uint64_t take = std::min<uint64_t>(room, blk.n() - from);
+                    if (take == blk.n() - from) {
+                        w->append(blk, from);
+                        from = blk.n();
+                    } else {
+                        ReadBlock part;  // records [from, from + take)
+                        part.bases.assign(blk.bases.begin() + (ptrdiff_t)blk.off[from], blk.bases.begin() + (ptrdiff_t)blk.off[from + take]);
+                        part.ids.assign(blk.ids, blk.id_off[from], blk.id_off[from + take] - blk.id_off[from]);
+                        for (uint64_t r = from + 1; r <= from + take; r++) {
+                            part.off.push_back(blk.off[r] - blk.off[from]);
+                            part.id_off.push_back(blk.id_off[r] - blk.id_off[from]);
+                        }
+                        w->append(part);
+                        from += take;
+                    }
+                    if (full()) {
+                        if (!emit(std::move(w))) return true;
+                        w = pool.get();
+                    }
+                }
+            }
+            par.close();
+            if (!serial_from_start) {
+                if (w->n() && !emit(std::move(w))) return true;
+                return true;
+            }
+        }
+        Record r;
+        while (rd.next(r)) {
+            if (skipped < read_offset) {
+                skipped++;
+                continue;
+            }
+            w->bases.insert(w->bases.end(), r.seq.begin(), r.seq.end());
+            w->off.push_back(w->bases.size());
+            w->ids += r.id;
+            w->ids.push_back('\0');
+            w->id_off.push_back(w->ids.size());
+            if (full()) {
+                if (!emit(std::move(w))) return true;
+                w = pool.get();
+            }
+        }
+        if (rd.error) return false;
+        if (w->n()) emit(std::move(w));
+        return true;
+    };
+
+    if (a.parse_only) {  // ingest self-check: counts and FNV-1a checksums of everything the binner would see
+        uint64_t n = 0, nb = 0, hb = 1469598103934665603ull, hi = 1469598103934665603ull, hl = 1469598103934665603ull;
+        auto fnv = [](uint64_t& h, const uint8_t* p, uint64_t len) {
+            for (uint64_t i = 0; i < len; i++) h = (h ^ p[i]) * 1099511628211ull;
+        };
+        bool ok = produce(a.batch_reads, [&](std::unique_ptr<ReadBlock> w) {
+            n += w->n();
+            nb += w->bases.size();
+            if (getenv("MTSV_PARSE_NOHASH")) {
+                pool.put(std::move(w));
+                return true;
+            }
+            fnv(hb, w->bases.data(), w->bases.size());
+            fnv(hi, (const uint8_t*)w->ids.data(), w->ids.size());
+            for (uint64_t r = 0; r < w->n(); r++) {
+                uint64_t len = w->off[r + 1] - w->off[r];
+                fnv(hl, (const uint8_t*)&len, 8);
+            }
+            return true;
+        });
+        if (!ok) {
+            logmsg("ERROR", "Unable to read from input file: " + rd.err_msg);
+            return 12;
+        }
+        printf("records=%llu bases=%llu bases_fnv=%016llx ids_fnv=%016llx lens_fnv=%016llx\n", (unsigned long long)n,
+               (unsigned long long)nb, (unsigned long long)hb, (unsigned long long)hi, (unsigned long long)hl);
+        return 0;
+    }
+
     FILE* out = fopen(a.results.c_str(), append ? "ab" : "wb");
     if (!out) {
         logmsg("ERROR", "Error running query: cannot open results file " + a.results);
@@ -365,18 +498,14 @@ int main(int argc, char** argv) {
         return 2;
     }
     logmsg("INFO", "Beginning queries.");
-    const clock_t t0 = clock();
     struct timespec w0;
     clock_gettime(CLOCK_MONOTONIC, &w0);
 
     // Three overlapped stages (the reference overlaps producer / workers / joiner the same way,
-    // vendor/cue/src/lib.rs:45-105): a reader thread parses FASTX into batches, this thread runs the
+    // vendor/cue/src/lib.rs:45-105): the producer parses FASTX into batches, this thread runs the
     // batches on the GPU, a writer thread formats and writes the result lines in input order.
     struct Work {
-        std::vector<uint8_t> bases;
-        std::vector<uint64_t> off{0};
-        std::string ids;
-        std::vector<uint64_t> id_off{0};
+        std::unique_ptr<ReadBlock> rb;
         mtsv_hit* hits = nullptr;
         uint64_t n_hits = 0;
     };
@@ -420,29 +549,16 @@ int main(int argc, char** argv) {
     };
 
     std::thread reader([&] {
-        auto w = std::make_unique<Work>();
-        Record r;
-        uint64_t skipped = 0;
-        while (!failed() && rd.next(r)) {
-            if (skipped < read_offset) {
-                skipped++;
-                continue;
-            }
-            w->bases.insert(w->bases.end(), r.seq.begin(), r.seq.end());
-            w->off.push_back(w->bases.size());
-            w->ids += r.id;
-            w->ids.push_back('\0');
-            w->id_off.push_back(w->ids.size());
-            if (w->off.size() - 1 >= a.batch_reads || w->bases.size() >= (1ull << 30)) {
-                parsed.push(std::move(w));
-                w = std::make_unique<Work>();
-            }
-        }
-        if (rd.error) {
+        bool ok = produce(a.batch_reads, [&](std::unique_ptr<ReadBlock> rb) {
+            if (failed()) return false;
+            auto w = std::make_unique<Work>();
+            w->rb = std::move(rb);
+            parsed.push(std::move(w));
+            return true;
+        });
+        if (!ok) {
             logmsg("ERROR", "Unable to read from input file: " + rd.err_msg);
             set_code(12);  // binner.rs:81-84
-        } else if (w->off.size() > 1) {
-            parsed.push(std::move(w));
         }
         parsed.close();
     });
@@ -450,35 +566,59 @@ int main(int argc, char** argv) {
     std::thread writer([&] {
         uint64_t total = 0;
         while (auto w = done.pop()) {
-            char* text = nullptr;
-            uint64_t len = 0;
-            int rc = mtsv_format_results(w->hits, w->n_hits, w->ids.data(), w->id_off.data(), w->off.size() - 1, long_fmt, &text, &len);
+            // write_assignments over slices of the batch's hits (cut between reads), one thread each
+            const uint64_t n_reads = w->rb->n();
+            const unsigned parts = w->n_hits >= (1u << 16) ? host_threads : 1;
+            std::vector<uint64_t> cut(parts + 1, w->n_hits);
+            cut[0] = 0;
+            for (unsigned k = 1; k < parts; k++) {
+                uint64_t c = std::max(cut[k - 1], w->n_hits * k / parts);
+                while (c > cut[k - 1] && c < w->n_hits && w->hits[c].read == w->hits[c - 1].read) c++;
+                cut[k] = c;
+            }
+            std::vector<char*> text(parts, nullptr);
+            std::vector<uint64_t> len(parts, 0);
+            std::vector<int> rc(parts, MTSV_OK);
+            std::vector<std::string> msg(parts);
+            auto fmt = [&](unsigned k) {
+                rc[k] = mtsv_format_results(w->hits + cut[k], cut[k + 1] - cut[k], w->rb->ids.data(), w->rb->id_off.data(), n_reads,
+                                            long_fmt, &text[k], &len[k]);
+                if (rc[k] != MTSV_OK) msg[k] = mtsv_last_error();  // thread-local
+            };
+            {
+                std::vector<std::thread> th;
+                for (unsigned k = 1; k < parts; k++) th.emplace_back(fmt, k);
+                fmt(0);
+                for (auto& t : th) t.join();
+            }
             mtsv_hits_free(w->hits);
-            if (rc != MTSV_OK) {
-                logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
-                set_code(2);
-                continue;
+            bool ok = true;
+            for (unsigned k = 0; k < parts; k++) {
+                if (rc[k] != MTSV_OK) {
+                    if (ok) logmsg("ERROR", "Error running query: " + msg[k]);
+                    set_code(2);
+                    ok = false;
+                } else if (ok && !failed() && len[k] && fwrite(text[k], 1, len[k], out) != len[k]) {
+                    logmsg("ERROR", "Error writing to result file");
+                    set_code(11);  // binner.rs:136-139
+                    ok = false;
+                }
+                mtsv_free(text[k]);
             }
-            bool ok = len == 0 || fwrite(text, 1, len, out) == len;
-            mtsv_free(text);
-            if (!ok) {
-                logmsg("ERROR", "Error writing to result file");
-                set_code(11);  // binner.rs:136-139
-                continue;
-            }
-            total += w->off.size() - 1;
+            pool.put(std::move(w->rb));
+            if (!ok) continue;
+            total += n_reads;
             logmsg("DEBUG", "taxonomic binning: " + std::to_string(total) + " reads done");
         }
     });
 
     while (auto w = parsed.pop()) {
         if (failed()) continue;  // drain
-        if (mtsv_bin_batch(ix, a.device, w->bases.data(), w->off.data(), w->off.size() - 1, &p, &w->hits, &w->n_hits) != MTSV_OK) {
+        if (mtsv_bin_batch(ix, a.device, w->rb->bases.data(), w->rb->off.data(), w->rb->n(), &p, &w->hits, &w->n_hits) != MTSV_OK) {
             logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
             set_code(2);
             continue;
         }
-        std::vector<uint8_t>().swap(w->bases);  // the writer needs only ids and hits
         done.push(std::move(w));
     }
     done.close();
@@ -491,7 +631,6 @@ int main(int argc, char** argv) {
     }
     struct timespec w1;
     clock_gettime(CLOCK_MONOTONIC, &w1);
-    (void)t0;
     char msg[160];
     snprintf(msg, sizeof msg, "All worker and result consumer threads terminated. Took %.3f seconds.",
              (w1.tv_sec - w0.tv_sec) + (w1.tv_nsec - w0.tv_nsec) * 1e-9);

@@ -1,0 +1,308 @@
+// fastx_ingest.hpp -- block-parallel FASTA/FASTQ ingest for mtsv-binner (the producer side of
+// get_fastx_and_write_matching_bin_ids, src/binner.rs:149-217; bio::io::{fasta,fastq} readers).
+//
+// Plain (not gzip-compressed) regular files are mapped and cut into blocks at record boundaries;
+// a pool of threads parses the blocks, the consumer takes them back in input order.  The parse of a
+// block is strict (FASTQ: exactly header / sequence / '+' / quality of equal length; FASTA: '>'
+// records) and must end exactly on the next block's boundary.  The first block that does not fit
+// (wrapped FASTQ, empty reads, truncated files, anything the serial reader would report) is handed
+// back as "irregular at byte offset X": every block before it is, by induction from offset 0,
+// exactly what the serial reader would have produced, and the caller continues with the serial
+// reader from X, which also produces the reference's error for broken input.
+#pragma once
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <condition_variable>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+namespace mtsv_ingest {
+
+struct ReadBlock {
+    std::vector<uint8_t> bases;
+    std::vector<uint64_t> off{0};     // n + 1 offsets into bases
+    std::string ids;                  // NUL-terminated ids, back to back
+    std::vector<uint64_t> id_off{0};  // n + 1 offsets into ids
+    uint64_t n() const { return off.size() - 1; }
+    void clear() {
+        bases.clear();
+        off.assign(1, 0);
+        ids.clear();
+        id_off.assign(1, 0);
+    }
+    // append records [from, b.n()) of b
+    void append(const ReadBlock& b, uint64_t from = 0) {
+        const uint64_t nb = b.n();
+        if (from >= nb) return;
+        const uint64_t b0 = b.off[from], i0 = b.id_off[from];
+        const uint64_t base_b = bases.size(), base_i = ids.size();
+        bases.insert(bases.end(), b.bases.begin() + (ptrdiff_t)b0, b.bases.end());
+        ids.append(b.ids, i0, std::string::npos);
+        off.reserve(off.size() + (nb - from));
+        id_off.reserve(id_off.size() + (nb - from));
+        for (uint64_t r = from + 1; r <= nb; r++) {
+            off.push_back(base_b + (b.off[r] - b0));
+            id_off.push_back(base_i + (b.id_off[r] - i0));
+        }
+    }
+};
+
+class ParallelFastx {
+   public:
+    enum Result { BLOCK = 0, END = 1, IRREGULAR = 2 };
+
+    ~ParallelFastx() { close(); }
+
+    // false: not a plain regular file (gzip magic, pipe, empty, mmap failure) -> use the serial reader
+    bool open(const std::string& path, bool fastq, unsigned threads, uint64_t block_bytes = 16ull << 20) {
+        fastq_ = fastq;
+        int fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0 || !S_ISREG(st.st_mode) || st.st_size < 2) {
+            ::close(fd);
+            return false;
+        }
+        size_ = (uint64_t)st.st_size;
+        void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) {
+            ::close(fd);
+            return false;
+        }
+        fd_ = fd;
+        data_ = (const uint8_t*)m;
+        if (data_[0] == 0x1f && data_[1] == 0x8b) {  // gzip magic (binner.rs:21-33)
+            close();
+            return false;
+        }
+        // block boundaries
+        bounds_.push_back(0);
+        for (uint64_t t = block_bytes; t < size_; t += block_bytes) {
+            uint64_t b = find_boundary(std::max(t, bounds_.back() + 1));
+            if (b != UINT64_MAX && b > bounds_.back() && b < size_) bounds_.push_back(b);
+        }
+        bounds_.push_back(size_);
+        n_blocks_ = bounds_.size() - 1;
+        window_ = 2 * std::max(1u, threads) + 2;
+        for (unsigned k = 0; k < std::max(1u, threads); k++) pool_.emplace_back([this] { worker(); });
+        return true;
+    }
+
+    // blocks come back in input order
+    Result next(ReadBlock& out, uint64_t* irregular_offset) {
+        if (consumed_ >= n_blocks_) return END;
+        std::unique_ptr<Parsed> p;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return done_.count(consumed_) != 0; });
+            p = std::move(done_[consumed_]);
+            done_.erase(consumed_);
+            consumed_++;
+        }
+        cv_.notify_all();
+        if (!p->ok) {
+            *irregular_offset = bounds_[consumed_ - 1];
+            stop();
+            return IRREGULAR;
+        }
+        std::swap(out, p->block);  // the caller's old buffers go back to the workers: no fresh pages per block
+        p->block.clear();
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            free_.push_back(std::move(p));
+        }
+        return BLOCK;
+    }
+
+    void close() {
+        stop();
+        if (data_) munmap((void*)data_, size_);
+        data_ = nullptr;
+        if (fd_ >= 0) ::close(fd_);
+        fd_ = -1;
+    }
+
+   private:
+    struct Parsed {
+        ReadBlock block;
+        bool ok = true;
+    };
+
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto& t : pool_)
+            if (t.joinable()) t.join();
+        pool_.clear();
+    }
+
+    // The mapping is only used to look for block boundaries (a few pages per block); block contents
+    // are pread() into a per-thread buffer: a copy out of the page cache, without one page fault per
+    // 4 KiB of input in a shared address space.
+    void worker() {
+        std::vector<uint8_t> buf;
+        for (;;) {
+            uint64_t k = next_block_.fetch_add(1);
+            if (k >= n_blocks_) return;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || k < consumed_ + window_; });
+                if (stop_) return;
+            }
+            std::unique_ptr<Parsed> p;
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!free_.empty()) {
+                    p = std::move(free_.back());
+                    free_.pop_back();
+                }
+            }
+            if (!p) p = std::make_unique<Parsed>();
+            const uint64_t s = bounds_[k], len = bounds_[k + 1] - s;
+            if (buf.size() < len) buf.resize(len);
+            uint64_t got = 0;
+            while (got < len) {
+                ssize_t r = pread(fd_, buf.data() + got, len - got, (off_t)(s + got));
+                if (r <= 0) break;
+                got += (uint64_t)r;
+            }
+            p->ok = got == len && (fastq_ ? parse_fastq(buf.data(), len, p->block) : parse_fasta(buf.data(), len, k == 0, k + 1 == n_blocks_, p->block));
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                done_[k] = std::move(p);
+            }
+            cv_.notify_all();
+        }
+    }
+
+    // [s, e) of the line starting at s, e = position of '\n' or end; next line starts at e + 1
+    uint64_t line_end(uint64_t s, uint64_t limit) const {
+        const void* nl = memchr(data_ + s, '\n', limit - s);
+        return nl ? (uint64_t)((const uint8_t*)nl - data_) : limit;
+    }
+
+    // first record start at or after t (a hint only: blocks are validated by the strict parse)
+    uint64_t find_boundary(uint64_t t) const {
+        const uint64_t scan_limit = std::min<uint64_t>(size_, t + (4ull << 20));
+        uint64_t s = line_end(t - 1, scan_limit) + 1;  // first line start after t-1
+        if (!fastq_) {
+            while (s < scan_limit) {
+                if (data_[s] == '>') return s;
+                s = line_end(s, scan_limit) + 1;
+            }
+            return UINT64_MAX;
+        }
+        while (s < scan_limit) {
+            if (data_[s] == '@') {
+                uint64_t l1 = line_end(s, size_) + 1;
+                uint64_t l2 = l1 < size_ ? line_end(l1, size_) + 1 : size_;
+                if (l2 < size_ && data_[l2] == '+') {
+                    uint64_t l3 = line_end(l2, size_) + 1;
+                    uint64_t l4 = l3 < size_ ? line_end(l3, size_) + 1 : size_;
+                    if (l4 >= size_ || data_[l4] == '@') return s;
+                }
+            }
+            s = line_end(s, scan_limit) + 1;
+        }
+        return UINT64_MAX;
+    }
+
+    static void push_id(ReadBlock& b, const uint8_t* h, uint64_t len) {  // first token after the marker
+        uint64_t e = 1;
+        while (e < len && h[e] != ' ' && h[e] != '\t') e++;
+        if (len > 1) b.ids.append((const char*)h + 1, e - 1);
+        b.ids.push_back('\0');
+        b.id_off.push_back(b.ids.size());
+    }
+
+    static uint64_t eol(const uint8_t* d, uint64_t s, uint64_t limit) {
+        const void* nl = memchr(d + s, '\n', limit - s);
+        return nl ? (uint64_t)((const uint8_t*)nl - d) : limit;
+    }
+
+    static bool parse_fastq(const uint8_t* d, uint64_t e, ReadBlock& b) {
+        b.clear();
+        b.bases.reserve(e / 2);
+        uint64_t p = 0;
+        while (p < e) {
+            uint64_t e0 = eol(d, p, e);
+            if (e0 >= e) return false;  // header without a sequence line inside the block
+            uint64_t p1 = e0 + 1, e1 = eol(d, p1, e);
+            if (e1 >= e) return false;
+            uint64_t p2 = e1 + 1, e2 = eol(d, p2, e);
+            if (e2 >= e) return false;
+            uint64_t p3 = e2 + 1, e3 = eol(d, p3, e);  // the last line may end at e without '\n'
+            uint64_t h_len = e0 - p, s_len = e1 - p1, q_len = e3 - p3;
+            if (h_len && d[e0 - 1] == '\r') h_len--;
+            if (s_len && d[e1 - 1] == '\r') s_len--;
+            if (q_len && d[e3 - 1] == '\r') q_len--;
+            if (h_len == 0 || d[p] != '@' || s_len == 0 || d[p1] == '+' || p2 >= e || d[p2] != '+' || q_len != s_len) return false;
+            push_id(b, d + p, h_len);
+            b.bases.insert(b.bases.end(), d + p1, d + p1 + s_len);
+            b.off.push_back(b.bases.size());
+            p = e3 + 1;
+        }
+        return p == e || p == e + 1;  // ended on the boundary (or on a final line without '\n')
+    }
+
+    static bool parse_fasta(const uint8_t* d, uint64_t e, bool first, bool last, ReadBlock& b) {
+        b.clear();
+        b.bases.reserve(e);
+        uint64_t p = 0;
+        if (first) {  // the serial reader skips blank lines before the first header
+            while (p < e) {
+                uint64_t le = eol(d, p, e);
+                uint64_t len = le - p;
+                if (len && d[le - 1] == '\r') len--;
+                if (len) break;
+                p = le + 1;
+            }
+            if (p >= e) return last;
+        }
+        if (d[p] != '>') return false;
+        while (p < e) {
+            uint64_t le = eol(d, p, e);
+            uint64_t len = le - p;
+            if (len && d[le - 1] == '\r') len--;
+            if (len && d[p] == '>') {
+                if (b.id_off.size() > 1) b.off.push_back(b.bases.size());  // close the previous record
+                push_id(b, d + p, len);
+            } else if (len) {
+                b.bases.insert(b.bases.end(), d + p, d + p + len);
+            }
+            p = le + 1;
+        }
+        b.off.push_back(b.bases.size());
+        return b.off.size() == b.id_off.size();
+    }
+
+    const uint8_t* data_ = nullptr;
+    int fd_ = -1;
+    uint64_t size_ = 0;
+    bool fastq_ = true;
+    std::vector<uint64_t> bounds_;
+    uint64_t n_blocks_ = 0, window_ = 4;
+    std::atomic<uint64_t> next_block_{0};
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::map<uint64_t, std::unique_ptr<Parsed>> done_;
+    std::vector<std::unique_ptr<Parsed>> free_;
+    uint64_t consumed_ = 0;
+    bool stop_ = false;
+    std::vector<std::thread> pool_;
+};
+
+}  // namespace mtsv_ingest

@@ -163,3 +163,39 @@ def test_mtsv_build_cli_writes_the_reference_layout(tmp_path):
     assert open(out2, "rb").read() == open(ref, "rb").read()
     assert subprocess.run([build, "-f", str(fa), "-i", str(out), "--sa-sample", "x"], capture_output=True).returncode == 101
     assert subprocess.run([build, "-f", str(tmp_path / "nope.fa"), "-i", str(out), "--device", "-1"], capture_output=True).returncode == 101
+
+
+@pytest.mark.gpu
+def test_parallel_ingest_and_formatting_equal_the_serial_pipeline(tmp_path):
+    """150 k reads: several ingest blocks (1 MiB), several batches, result formatting split over host
+    threads (>= 65536 hits per batch).  Output must be byte-identical, in order, to the single-threaded
+    serial pipeline, and as a set of lines to the oracle's formatter over the oracle's hits."""
+    import numpy as np
+    from oracle import oracle as O
+
+    ix = M.MGIndex.synth(77, 8, 2, 20000, threads=4)
+    idx = tmp_path / "p.idx"
+    ix.write(str(idx))
+    bases, off = M.synth_reads(ix, 3, 150000, 100)
+    lens = np.diff(off)
+    fq = tmp_path / "p.fastq"
+    with open(fq, "wb") as f:
+        for i in range(len(lens)):
+            s = bases[off[i]:off[i + 1]].tobytes()
+            f.write(b"@q%d extra words\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
+    outs = {}
+    for name, env in (("serial", {"MTSV_SERIAL_INGEST": "1", "MTSV_HOST_THREADS": "1"}),
+                      ("par", {"MTSV_HOST_THREADS": "6", "MTSV_INGEST_BLOCK": str(1 << 20)})):
+        out = tmp_path / f"{name}.txt"
+        r = subprocess.run([BIN, "--fastq", str(fq), "-i", str(idx), "-m", str(out), "--force-overwrite", "--batch-reads", "70000"],
+                           capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout + r.stderr
+        outs[name] = open(out, "rb").read()
+    assert outs["par"] == outs["serial"]
+    orc = O.Index.read(str(idx))
+    hits, _ = orc.bin_batch(bases, off, O.default_params(), threads=8)
+    want = set()
+    cuts = np.flatnonzero(np.diff(hits["read"])) + 1          # hits are ordered by read
+    for grp in np.split(hits, cuts):
+        want.add(O.format_line(f"q{grp['read'][0]}", grp).rstrip("\n"))
+    assert set(outs["par"].decode().splitlines()) == want

@@ -1,0 +1,137 @@
+"""Block-parallel FASTA/FASTQ ingest of mtsv-binner (mtsv_tools_amd/csrc/fastx_ingest.hpp) against the
+serial reader that mirrors bio::io::{fasta,fastq} as used at src/binner.rs:169-199.  `--parse-only`
+prints record / base counts and checksums of ids, bases and read lengths; it needs no index or GPU."""
+import os
+import random
+import subprocess
+
+import pytest
+
+BIN = os.path.join(os.path.dirname(__file__), "..", "mtsv_tools_amd", "bin", "mtsv-binner")
+
+
+def parse_only(path, fastq, serial=False, block=None, threads=4, offset=0, batch=None):
+    env = dict(os.environ, MTSV_HOST_THREADS=str(threads))
+    if serial:
+        env["MTSV_SERIAL_INGEST"] = "1"
+    if block:
+        env["MTSV_INGEST_BLOCK"] = str(block)
+    cmd = [BIN, "--parse-only", "--fastq" if fastq else "--fasta", str(path), "--read-offset", str(offset)]
+    if batch:
+        cmd += ["--batch-reads", str(batch)]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=120)
+    last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    return r.returncode, last
+
+
+def rand_seq(rng, n):
+    return "".join(rng.choice("ACGTN") for _ in range(n))
+
+
+def fastq_text(rng, n, crlf=False, at_quality=True):
+    nl = "\r\n" if crlf else "\n"
+    out = []
+    for i in range(n):
+        L = rng.randint(1, 200)
+        q = "".join(rng.choice("@+IJK#5") for _ in range(L))
+        if at_quality and i % 3 == 0:
+            q = "@" + q[1:]            # quality lines that look like headers
+        if i % 5 == 0:
+            q = "+" + q[1:]
+        out.append(f"@r{i} desc {i}{nl}{rand_seq(rng, L)}{nl}+{nl}{q}{nl}")
+    return "".join(out)
+
+
+@pytest.mark.parametrize("crlf", [False, True])
+def test_fastq_blocks_equal_serial(tmp_path, crlf):
+    rng = random.Random(5)
+    p = tmp_path / "a.fq"
+    p.write_text(fastq_text(rng, 3000, crlf=crlf), newline="")
+    want = parse_only(p, True, serial=True)
+    assert want[0] == 0 and want[1].startswith("records=3000 ")
+    for block in (1, 257, 4096, 100000, None):
+        for threads in (1, 5):
+            assert parse_only(p, True, block=block, threads=threads) == want
+    # read offset and batch cutting
+    w2 = parse_only(p, True, serial=True, offset=1234, batch=100)
+    assert w2[1].startswith("records=1766 ")
+    assert parse_only(p, True, block=4096, offset=1234, batch=100) == w2
+    assert parse_only(p, True, block=4096, offset=5000) == parse_only(p, True, serial=True, offset=5000)
+
+
+def test_fastq_no_trailing_newline_and_blank_tail(tmp_path):
+    rng = random.Random(6)
+    text = fastq_text(rng, 500)
+    for name, t in (("nonl.fq", text[:-1]), ("blank.fq", text + "\n\n"), ("one.fq", "@x\nACGT\n+\nIIII")):
+        p = tmp_path / name
+        p.write_text(t)
+        want = parse_only(p, True, serial=True)
+        assert want[0] == 0
+        assert parse_only(p, True, block=1000) == want
+
+
+def test_wrapped_fastq_falls_back_to_the_serial_reader(tmp_path):
+    rng = random.Random(7)
+    recs = []
+    for i in range(800):
+        L = rng.randint(50, 150)
+        s, q = rand_seq(rng, L), "".join(rng.choice("@+IJ") for _ in range(L))
+        if i >= 400:  # second half: sequence and quality wrapped over several lines
+            s = "\n".join(s[k:k + 40] for k in range(0, L, 40))
+            q = "\n".join(q[k:k + 40] for k in range(0, L, 40))
+        recs.append(f"@w{i}\n{s}\n+w{i}\n{q}\n")
+    p = tmp_path / "w.fq"
+    p.write_text("".join(recs))
+    want = parse_only(p, True, serial=True)
+    assert want[0] == 0 and want[1].startswith("records=800 ")
+    for block in (500, 5000, None):
+        assert parse_only(p, True, block=block) == want
+
+
+def test_broken_fastq_reports_like_the_serial_reader(tmp_path):
+    rng = random.Random(8)
+    text = fastq_text(rng, 300)
+    cases = {"trunc.fq": text[: len(text) // 2 + 7], "nohdr.fq": text.replace("@r150 ", "r150 ", 1),
+             "qlen.fq": text + "@z\nACGT\n+\nII\n"}
+    for name, t in cases.items():
+        p = tmp_path / name
+        p.write_text(t)
+        want = parse_only(p, True, serial=True)
+        got = parse_only(p, True, block=2000)
+        assert got[0] == want[0], name
+        if want[0] == 0:
+            assert got == want
+        else:
+            assert want[0] == 12   # binner.rs:81-84
+
+
+def test_fasta_blocks_equal_serial(tmp_path):
+    rng = random.Random(9)
+    recs = ["\n\n"]
+    for i in range(1500):
+        L = rng.randint(0, 400)
+        s = rand_seq(rng, L)
+        width = rng.choice((60, 70, 1000))
+        body = "\n".join(s[k:k + width] for k in range(0, L, width))
+        recs.append(f">s{i}\tsome text\n{body}\n" + ("\n" if i % 7 == 0 else ""))
+    recs.append(">")  # empty id, no sequence, no newline
+    p = tmp_path / "a.fa"
+    p.write_text("".join(recs))
+    want = parse_only(p, False, serial=True)
+    assert want[0] == 0 and want[1].startswith("records=1501 ")
+    for block in (1, 300, 10000, None):
+        assert parse_only(p, False, block=block, threads=3) == want
+    bad = tmp_path / "bad.fa"
+    bad.write_text("ACGT\n>x\nACGT\n")
+    assert parse_only(bad, False, serial=True)[0] == 12
+    assert parse_only(bad, False, block=4)[0] == 12
+
+
+def test_gzip_input_uses_the_serial_reader(tmp_path):
+    import gzip
+    rng = random.Random(10)
+    text = fastq_text(rng, 200)
+    (tmp_path / "a.fq").write_text(text)
+    with gzip.open(tmp_path / "a.fq.gz", "wt") as f:
+        f.write(text)
+    assert parse_only(tmp_path / "a.fq.gz", True) == parse_only(tmp_path / "a.fq", True, serial=True)

@@ -15,12 +15,33 @@ with open("/tmp/cli.fastq", "wb") as f:
     for lo in range(0, n, 100000):
         f.write(b"".join(b"@r%d\n%s\n+\n%s\n" % (i, b[i].tobytes(), q) for i in range(lo, min(n, lo + 100000))))
 print("fastq written", time.time() - t0, os.path.getsize("/tmp/cli.fastq") / 1e6, "MB")
-subprocess.check_call("gzip -1 -k -f /tmp/cli.fastq", shell=True)
+do_gz = n <= 10_000_000
+if do_gz:
+    subprocess.check_call("gzip -1 -k -f /tmp/cli.fastq", shell=True)
 exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mtsv_tools_amd", "bin", "mtsv-binner")
-for path in ("/tmp/cli.fastq", "/tmp/cli.fastq.gz"):
-    for extra in ([], ["--batch-reads", "262144"]):
-        t0 = time.time()
-        subprocess.check_call([exe, "--fastq", path, "-i", "/tmp/cli.idx", "-m", "/tmp/cli.out", "--force-overwrite", *extra],
-                              stdout=subprocess.DEVNULL)
-        dt = time.time() - t0
-        print(f"{os.path.basename(path)} {extra}: {dt:.2f} s  {n / dt / 1e6:.2f} M reads/s  lines={sum(1 for _ in open('/tmp/cli.out'))}")
+import re
+
+
+def run(path, extra=(), env=None):
+    e = dict(os.environ, **(env or {}))
+    t0 = time.time()
+    out = subprocess.run([exe, "--fastq", path, "-i", "/tmp/cli.idx", "-m", "/tmp/cli.out", "--force-overwrite", *extra],
+                         stdout=subprocess.PIPE, text=True, env=e, check=True).stdout
+    dt = time.time() - t0
+    q = float(re.search(r"Took ([0-9.]+) seconds", out).group(1))   # queries only (after index load + upload)
+    lines = sum(1 for _ in open("/tmp/cli.out"))
+    print(f"{os.path.basename(path)} {list(extra)} {env or ''}: wall {dt:.2f} s, queries {q:.2f} s = {n / q / 1e6:.2f} M reads/s, lines={lines}", flush=True)
+    return lines
+
+
+for env in ({"MTSV_SERIAL_INGEST": "1"}, {"MTSV_HOST_THREADS": "2"}, {"MTSV_HOST_THREADS": "4"}, {"MTSV_HOST_THREADS": "8"}, {"MTSV_HOST_THREADS": "16"}):
+    t0 = time.time()
+    subprocess.check_call([exe, "--parse-only", "--fastq", "/tmp/cli.fastq"], stdout=subprocess.DEVNULL, env=dict(os.environ, MTSV_PARSE_NOHASH="1", **env))
+    print(f"parse-only {env}: {time.time() - t0:.2f} s", flush=True)
+ref = run("/tmp/cli.fastq", env={"MTSV_SERIAL_INGEST": "1", "MTSV_HOST_THREADS": "1"})
+for env in ({"MTSV_HOST_THREADS": "4"}, {"MTSV_HOST_THREADS": "8"}, {"MTSV_HOST_THREADS": "16"}):
+    assert run("/tmp/cli.fastq", env=env) == ref
+run("/tmp/cli.fastq", ["--batch-reads", "262144"])
+run("/tmp/cli.fastq", ["--batch-reads", "524288"])
+if do_gz:
+    run("/tmp/cli.fastq.gz")
