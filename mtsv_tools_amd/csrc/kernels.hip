@@ -1223,21 +1223,62 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
     }
 }
 
+// 16 window columns of a candidate in the order the sweep consumes them, as codes clamped to 0..4
+// (4 = matches nothing).  Forward strand: text[start+j0 ..]; reverse strand: text[end-1-j0], downwards
+// (complementing is folded into the match table).  Columns past the window are don't-cares.
+__device__ inline uint32_t clamp_codes4(uint32_t x) {
+    const uint32_t t = x & 0x04040404u;
+    return t | (x & 0x03030303u & ~((t >> 1) | (t >> 2)));
+}
+__device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint32_t end, uint32_t strand, uint32_t j0) {
+    uint4 r;
+    if (!strand) {
+        r = load16(ix.text, ix.n, start + j0);
+    } else if (end >= j0 + 16) {
+        const uint4 v = load16(ix.text, ix.n, end - j0 - 16);
+        r.x = __builtin_amdgcn_perm(0, v.w, 0x00010203u);
+        r.y = __builtin_amdgcn_perm(0, v.z, 0x00010203u);
+        r.z = __builtin_amdgcn_perm(0, v.y, 0x00010203u);
+        r.w = __builtin_amdgcn_perm(0, v.x, 0x00010203u);
+    } else {  // fewer than 16 symbols left above text position 0 (only the first bins of an index)
+        uint32_t w[4] = {0, 0, 0, 0};
+        for (uint32_t i = 0; i < 16; i++) {
+            const uint32_t code = end >= j0 + 1 + i ? ix.text[end - j0 - 1 - i] : 7u;
+            w[i >> 2] |= code << (8 * (i & 3));
+        }
+        r = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    r.x = clamp_codes4(r.x);
+    r.y = clamp_codes4(r.y);
+    r.z = clamp_codes4(r.z);
+    r.w = clamp_codes4(r.w);
+    return r;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Alternative verification order ("edit first"): acceptance is the conjunction of two pure
 // predicates, SW >= L - 2*ED and edits <= ED (index.rs:406,410), and for reads up to 253 bases the
 // SW score is the exact local score, for which edits <= ED implies SW >= L - 2*ED (an alignment with
 // e edits scores >= L - 2e; tests/test_oracle.py).  So for such reads edits <= ED alone decides.
 // k_edit_myers computes Aligner::min_edit_distance (align.rs:28-85: first row 0, answer = min of
-// the last row) with Myers' bit-vector recurrence, one lane per candidate, W 64-bit words per
-// column.  Read 'N' matches nothing (index.rs:272-279), reference 'N' matches nothing either.
+// the last row) with Myers' bit-vector recurrence, one lane per candidate, W 32-bit words per
+// column, match masks in LDS.  Read 'N' matches nothing (index.rs:272-279), reference 'N' matches nothing either.
 // ---------------------------------------------------------------------------------------------
-template <int W>
+template <int W>  // W 32-bit words per column: reads of up to 32*W bases
 __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a) {
+    // match masks of the lane's read, one row per window symbol (A C G T, other), word-major so that a
+    // lane's reads are conflict-free whatever row it picks.  The read sits at the TOP of the 32*W rows
+    // (its last base is bit 31 of word W-1); the rows below it are wildcard rows whose vertical deltas
+    // start at 0: they stay 0 in every column, i.e. they reproduce the all-zero first row of
+    // align.rs:28-85 right under the read's first base, and the running score is simply the carry out
+    // of the last word.
+    __shared__ uint32_t eq_tab[5][W][256];
+    const uint32_t tid = threadIdx.x;
     const uint32_t n_work = *a.wl_count;
     const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
                                                : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
     const uint32_t lane = lane_id();
+    const uint32_t* bases32 = reinterpret_cast<const uint32_t*>(a.bases);
     unsigned long long verified = 0, wbytes = 0;
     // wave-uniform slice of the worklist, claimed 64 items at a time; a lane whose candidate passed
     // (or whose TaxId chain ended) takes the next item, a lane whose candidate failed keeps its read
@@ -1246,7 +1287,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     bool active = false, exhausted = false;
     uint32_t g = 0, o = 0, L = 0, ED = 0, strand = 0;
     bool thr_wrapped = false, hopeless = false;
-    uint64_t eqA[W], eqC[W], eqG[W], eqT[W];
+    uint32_t pv0[W];  // vertical +1 deltas of column 0: the read's rows only
     for (;;) {
         unsigned long long need = __ballot(!active);
         if (need) {
@@ -1269,31 +1310,51 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                 L = a.read_off[r_ + 1] - b0;
                 ED = (uint32_t)ceil((double)L * a.edit_rate);
                 thr_wrapped = 2ull * ED > (uint64_t)L;
-                const uint8_t* read = a.bases + b0;
-                // match masks of the FORWARD read; the reverse strand walks the window backwards with
+                // masks of the FORWARD read; the reverse strand walks the window backwards with
                 // complemented symbols instead (edit distance is invariant under reversing both strings)
-#pragma unroll
-                for (int k = 0; k < W; k++) {
-                    uint64_t mA = 0, mC = 0, mG = 0, mT = 0;
-                    for (uint32_t bq = 0; bq < 64; bq += 4) {
-                        uint32_t p = k * 64 + bq;
-                        if (p >= L) break;
-#pragma unroll
-                        for (int q = 0; q < 4; q++) {
-                            uint32_t code = p + q < L ? base_code(read[p + q]) : 7u;
-                            uint64_t bit = 1ull << (bq + q);
-                            mA |= code == 0 ? bit : 0;
-                            mC |= code == 1 ? bit : 0;
-                            mG |= code == 2 ? bit : 0;
-                            mT |= code == 3 ? bit : 0;
-                        }
-                    }
-                    eqA[k] = mA; eqC[k] = mC; eqG[k] = mG; eqT[k] = mT;
-                }
-                // edits >= number of read positions that match nothing (N): see k_evaluate
+                const int pad = 32 * W - (int)L;
                 uint32_t matchable = 0;
 #pragma unroll
-                for (int k = 0; k < W; k++) matchable += __popcll(eqA[k] | eqC[k] | eqG[k] | eqT[k]);
+                for (int k = 0; k < W; k++) {
+                    // rows 32k .. 32k+31 hold read positions q0 .. q0+31 (negative: wildcard rows)
+                    const int q0 = 32 * k - pad;
+                    uint32_t mA = 0, mC = 0, mG = 0, mT = 0, wild = 0;
+                    if (q0 + 31 >= 0) {
+                        const long long byte0 = (long long)b0 + q0;  // may point before this read (or the buffer)
+                        const long long w0 = byte0 >> 2;
+                        const uint32_t sh = (uint32_t)(byte0 & 3);
+                        uint32_t d[9];
+#pragma unroll
+                        for (int j = 0; j < 9; j++) d[j] = (w0 + j >= 0 && q0 + 4 * j + 3 >= 0) ? bases32[w0 + j] : 0u;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            const uint32_t four = __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh);
+#pragma unroll
+                            for (int q = 0; q < 4; q++) {
+                                const int bit_i = 4 * j + q;
+                                const uint32_t code = fast_code((four >> (8 * q)) & 0xffu);
+                                const uint32_t bit = 1u << bit_i;
+                                const bool real = q0 + bit_i >= 0;
+                                mA |= (real && code == 0) ? bit : 0u;
+                                mC |= (real && code == 1) ? bit : 0u;
+                                mG |= (real && code == 2) ? bit : 0u;
+                                mT |= (real && code == 3) ? bit : 0u;
+                                wild |= real ? 0u : bit;
+                            }
+                        }
+                    } else {
+                        wild = 0xffffffffu;
+                    }
+                    matchable += __popc(mA | mC | mG | mT);
+                    // reverse strand: the window is walked backwards and row c answers for the complement of c
+                    eq_tab[0][k][tid] = (strand ? mT : mA) | wild;
+                    eq_tab[1][k][tid] = (strand ? mG : mC) | wild;
+                    eq_tab[2][k][tid] = (strand ? mC : mG) | wild;
+                    eq_tab[3][k][tid] = (strand ? mA : mT) | wild;
+                    eq_tab[4][k][tid] = wild;
+                    pv0[k] = ~wild;
+                }
+                // edits >= number of read positions that match nothing (N): see k_evaluate
                 hopeless = thr_wrapped || L - matchable > ED;
                 active = true;
             }
@@ -1314,53 +1375,47 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
         } else if (active) {
             const uint4 c = a.cand[g];
             const DevBin bin = ix.bins[c.z];
-            uint64_t Pv[W], Mv[W];
+            uint32_t Pv[W], Mv[W];
 #pragma unroll
             for (int k = 0; k < W; k++) {
-                Pv[k] = ~0ull;
+                Pv[k] = pv0[k];
                 Mv[k] = 0;
             }
             const uint32_t Wn = c.y - c.x;
-            const uint32_t last_blk = (L - 1) / 64, last_bit = (L - 1) & 63;
             int score = (int)L, best = (int)L;  // D[L][0] = L
-            uint4 nxt4 = Wn ? load16(ix.text, ix.n, strand ? (c.y >= 16 ? c.y - 16 : 0) : c.x) : make_uint4(0, 0, 0, 0);
+            uint4 nxt4 = Wn ? fetch_cols(ix, c.x, c.y, strand, 0) : make_uint4(0, 0, 0, 0);
+            const uint32_t* lane_tab = &eq_tab[0][0][tid];
             for (uint32_t j0 = 0; j0 < Wn; j0 += 16) {
                 const uint4 cur = nxt4;
-                const uint32_t jn = j0 + 16;
-                if (jn < Wn) {  // prefetch the next 16 columns
-                    uint32_t pos = strand ? (c.y >= jn + 16 ? c.y - jn - 16 : 0) : c.x + jn;
-                    nxt4 = load16(ix.text, ix.n, pos);
-                }
+                if (j0 + 16 < Wn) nxt4 = fetch_cols(ix, c.x, c.y, strand, j0 + 16);  // prefetch the next 16 columns
                 const uint32_t lim = min(16u, Wn - j0);
-                // reverse walk: the chunk holds text[c.y-j0-16 .. c.y-j0), consumed from its top; when the
-                // start clamps at text position 0 the chunk is aligned there instead
-                const uint32_t rev_base = strand ? (c.y >= j0 + 16 ? 0u : (j0 + 16 - c.y)) : 0u;
-                for (uint32_t jj = 0; jj < lim; jj++) {
-                    uint32_t bi = strand ? (15u - jj - rev_base) : jj;
-                    uint32_t word = bi < 4 ? cur.x : bi < 8 ? cur.y : bi < 12 ? cur.z : cur.w;
-                    uint32_t tc = (word >> ((bi & 3) * 8)) & 0xffu;
-                    if (strand) tc = tc < 4 ? 3 - tc : tc;  // complement
-                    uint64_t hp = 0, hm = 0;  // horizontal delta entering block 0 is 0 (first row all zeros)
 #pragma unroll
-                    for (int k = 0; k < W; k++) {
-                        uint64_t Eq = tc == 0 ? eqA[k] : (tc == 1 ? eqC[k] : (tc == 2 ? eqG[k] : (tc == 3 ? eqT[k] : 0ull)));
-                        const uint64_t pv = Pv[k], mv = Mv[k];
-                        const uint64_t Xv = Eq | mv;
-                        Eq |= hm;
-                        const uint64_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-                        uint64_t Ph = mv | ~(Xh | pv);
-                        uint64_t Mh = pv & Xh;
-                        int d = (int)((Ph >> last_bit) & 1) - (int)((Mh >> last_bit) & 1);
-                        score += ((uint32_t)k == last_blk) ? d : 0;
-                        const uint64_t op = Ph >> 63, om = Mh >> 63;
-                        Ph = (Ph << 1) | hp;
-                        Mh = (Mh << 1) | hm;
-                        Pv[k] = Mh | ~(Xv | Ph);
-                        Mv[k] = Ph & Xv;
-                        hp = op;
-                        hm = om;
+                for (int jj = 0; jj < 16; jj++) {
+                    if ((uint32_t)jj < lim) {  // predicated, not a break: keeps the 16 columns unrolled
+                        const uint32_t word = jj < 4 ? cur.x : jj < 8 ? cur.y : jj < 12 ? cur.z : cur.w;
+                        const uint32_t tc = (word >> ((jj & 3) * 8)) & 0xffu;
+                        const uint32_t* row = lane_tab + tc * (W * 256);
+                        uint32_t hp = 0, hm = 0;  // horizontal delta entering word 0 is 0 (first row all zeros)
+#pragma unroll
+                        for (int k = 0; k < W; k++) {
+                            uint32_t Eq = row[k * 256];
+                            const uint32_t pv = Pv[k], mv = Mv[k];
+                            const uint32_t Xv = Eq | mv;
+                            Eq |= hm;
+                            const uint32_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
+                            uint32_t Ph = mv | ~(Xh | pv);
+                            uint32_t Mh = pv & Xh;
+                            const uint32_t op = Ph >> 31, om = Mh >> 31;
+                            Ph = (Ph << 1) | hp;
+                            Mh = (Mh << 1) | hm;
+                            Pv[k] = Mh | ~(Xv | Ph);
+                            Mv[k] = Ph & Xv;
+                            hp = op;
+                            hm = om;
+                        }
+                        score += (int)hp - (int)hm;  // the read's last base is bit 31 of the last word
+                        best = min(best, score);
                     }
-                    best = min(best, score);
                 }
             }
             verified++;
@@ -1545,12 +1600,15 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
 
 void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256), 256 * 8));
-    uint32_t W = (max_len + 63) / 64;
+    uint32_t W = (max_len + 31) / 32;
 #define MYERS_CASE(WW) hipLaunchKernelGGL(k_edit_myers<WW>, dim3(blocks), dim3(256), 0, s, ix, a)
-    if (W <= 1) MYERS_CASE(1);
-    else if (W <= 2) MYERS_CASE(2);
+    if (W <= 2) MYERS_CASE(2);
     else if (W <= 3) MYERS_CASE(3);
-    else MYERS_CASE(4);
+    else if (W <= 4) MYERS_CASE(4);
+    else if (W <= 5) MYERS_CASE(5);
+    else if (W <= 6) MYERS_CASE(6);
+    else if (W <= 7) MYERS_CASE(7);
+    else MYERS_CASE(8);
 #undef MYERS_CASE
 }
 
