@@ -68,7 +68,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_heavy_list, ns, &bytes);
     dev_alloc(&d_out_off, ns + 1, &bytes);
     dev_alloc(&d_tile_sums, (uint64_t)scan_tiles((uint32_t)ns) + 1, &bytes);
-    dev_alloc(&d_counters, 8, &bytes);
+    dev_alloc(&d_counters, kCounters, &bytes);
     dev_alloc(&d_hit_row, hit_cap, &bytes);
     dev_alloc(&d_hit_ref, hit_cap, &bytes);
     dev_alloc(&d_hit_q, hit_cap, &bytes);
@@ -81,7 +81,8 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_cand_status, hit_cap, &bytes);
     dev_alloc(&d_worklist, hit_cap, &bytes);
     dev_alloc(&d_hits, hits_cap, &bytes);
-    HIP_CHECK(hipHostMalloc((void**)&h_counters, 8 * sizeof(uint64_t)));
+    HIP_CHECK(hipHostMalloc((void**)&h_counters, kCounters * sizeof(uint64_t)));
+    if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
 }
@@ -138,7 +139,7 @@ void Batch::begin_run(const mtsv_params& p) {
     memset(&stats, 0, sizeof stats);
     memset(stage_acc, 0, sizeof stage_acc);
     n_hits_total = 0;
-    HIP_CHECK(hipMemsetAsync(d_counters, 0, 8 * sizeof(uint64_t), stream));
+    HIP_CHECK(hipMemsetAsync(d_counters, 0, kCounters * sizeof(uint64_t), stream));
     HIP_CHECK(hipEventRecord(ev[8], stream));
 }
 
@@ -254,11 +255,50 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             a.worklist = d_worklist;
             a.wl_count = (const uint32_t*)(d_counters + 1);
             a.wl_cursor = (uint32_t*)(d_counters + 7);
-            if (verify_mode == 1 && slice_max_len <= 253)
-                launch_edit_myers(stream, v, a, total_hits, slice_max_len);
-            else
-                launch_evaluate(stream, v, a, total_hits, slice_max_len);
             stats.n_rounds = 1;
+            if (verify_mode == 1 && slice_max_len <= 253) {
+                launch_edit_myers(stream, v, a, total_hits, slice_max_len);
+            } else if (sw_pairs && slice_max_len <= 253) {
+                // Reference order, split by predicate: k_sw_pairs runs the prefilter of index.rs:406 two
+                // candidates per group, k_edit_myers the edit distance of :407-410 on those that passed.
+                // A candidate that passes the first and fails the second sends its TaxId's next
+                // candidate to another round (rare); rounds end when nothing is left.
+                // counters: [8] SW cursor, [9] pass count, [10] Myers cursor, [11]/[12] next-round counts
+                uint32_t* pass_list = (uint32_t*)d_hit_key;                       // coalesce scratch is free now
+                uint32_t* next_lists[2] = {(uint32_t*)d_cand_tmp, (uint32_t*)d_cand_tmp + hit_cap};
+                const uint32_t* wl = d_worklist;
+                const uint32_t* wl_count = (const uint32_t*)(d_counters + 1);
+                uint64_t items = total_hits;
+                for (uint32_t round = 0;; round++) {
+                    uint64_t* next_slot = d_counters + 11 + (round & 1);
+                    HIP_CHECK(hipMemsetAsync(d_counters + 8, 0, 3 * sizeof(uint64_t), stream));
+                    HIP_CHECK(hipMemsetAsync(next_slot, 0, sizeof(uint64_t), stream));
+                    EvalArgs sw = a;
+                    sw.worklist = wl;
+                    sw.wl_count = wl_count;
+                    sw.wl_cursor = (uint32_t*)(d_counters + 8);
+                    sw.pass_list = pass_list;
+                    sw.pass_count = (uint32_t*)(d_counters + 9);
+                    launch_sw_pairs(stream, v, sw, items, slice_max_len);
+                    EvalArgs my = a;
+                    my.worklist = pass_list;
+                    my.wl_count = (const uint32_t*)(d_counters + 9);
+                    my.wl_cursor = (uint32_t*)(d_counters + 10);
+                    my.next_list = next_lists[round & 1];
+                    my.next_count = (uint32_t*)next_slot;
+                    launch_edit_myers(stream, v, my, items, slice_max_len, true);
+                    HIP_CHECK(hipMemcpyAsync(h_counters + 11, next_slot, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipStreamSynchronize(stream));
+                    const uint64_t n_next = h_counters[11] & 0xffffffffull;
+                    if (n_next == 0) break;
+                    stats.n_rounds++;
+                    wl = next_lists[round & 1];
+                    wl_count = (const uint32_t*)next_slot;
+                    items = n_next;
+                }
+            } else {
+                launch_evaluate(stream, v, a, total_hits, slice_max_len);
+            }
             launch_resolve(stream, nstr, p.max_candidates, p.max_assignments, d_strand_off, d_strand_ncand, d_cand_status,
                            d_out, d_strand_nout);
         }

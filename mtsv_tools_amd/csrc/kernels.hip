@@ -1223,6 +1223,295 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// K4b: the SW prefilter alone, two candidates per sweep (reads up to 253 bases, where the score of
+// ssw.c's byte kernel is the exact local score -- see k_evaluate).  A 16-lane group owns two
+// candidates at a time, A in the low and B in the high 16-bit half of every register; the two
+// recurrences share all packed instructions:
+//     H + 1 = max(1, diag + 2*[match], up + 1 - 1, left + 1 - 1)            (ssw.c:123-328 with the
+//     matrix of ssw/src/lib.rs:11-16 and gap 1/1; codes are kept pre-shifted so that one saturating
+//     subtraction of the XOR of read and window code yields 2*[match])
+// The reference consumes only the predicate score >= L - 2*ED (index.rs:406), so a half is decided as
+// soon as its running maximum reaches the threshold, or an exact bound shows it cannot any more;
+// the sweep of a pair ends when both halves are decided.  A candidate that passes goes to pass_list
+// for the edit distance (k_edit_myers in list mode, index.rs:407-410); one that fails hands the half
+// to the next candidate of its TaxId (index.rs:393), as in k_evaluate.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
+__device__ inline upk16 as_u2(uint32_t v) { return __builtin_bit_cast(upk16, v); }
+__device__ inline uint32_t as_bits(upk16 v) { return __builtin_bit_cast(uint32_t, v); }
+__device__ inline uint32_t pku_max(uint32_t a, uint32_t b) { return as_bits(__builtin_elementwise_max(as_u2(a), as_u2(b))); }
+__device__ inline uint32_t pku_add(uint32_t a, uint32_t b) { return as_bits(as_u2(a) + as_u2(b)); }
+__device__ inline uint32_t pku_sub(uint32_t a, uint32_t b) { return as_bits(as_u2(a) - as_u2(b)); }
+__device__ inline uint32_t pku_satsub(uint32_t a, uint32_t b) { return as_bits(__builtin_elementwise_sub_sat(as_u2(a), as_u2(b))); }
+
+enum : uint32_t { HF_EMPTY = 0, HF_SWEEP = 1, HF_PASS = 2, HF_FAIL = 3 };
+
+template <int R>
+__global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
+    constexpr int GS = 16;
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRing];
+    __shared__ uint32_t pend_all[256 / kWave][kWave + 8];  // passed candidates, flushed with one atomic per ~64
+    const uint32_t lane = lane_id();
+    const uint32_t gl = lane & (GS - 1);
+    uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
+    uint32_t pend = 0;  // wave-uniform
+    const uint32_t n_work = *a.wl_count;
+    const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
+                                               : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
+    const uint32_t ONE = 0x00010001u, TWO = 0x00020002u;
+
+    uint32_t phase = PH_FETCH;
+    uint32_t loc = 0, loc_end = 0;
+    bool drained = false;
+    // per-half state; index 0 = low half
+    uint32_t st[2] = {HF_EMPTY, HF_EMPTY};
+    uint32_t g[2] = {0, 0}, o[2] = {0, 0}, L[2] = {0, 0}, thr[2] = {0, 0}, Wn[2] = {0, 0}, wstart[2] = {0, 0};
+    bool chain[2] = {false, false}, hopeless[2] = {false, false};
+    uint32_t qc2[R];  // read codes << 1, both halves
+    uint32_t h[R], up_prev = 0, best = 0;
+    uint32_t cn[2] = {14, 14};
+    uint32_t t = 0, steps = 0;
+    unsigned long long verified = 0, wbytes = 0;
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        qc2[r] = 0x000c000cu;  // code 6 << 1 in both halves: matches nothing
+        h[r] = 0;
+    }
+
+    for (;;) {
+        if (phase == PH_FETCH) {
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                // a half keeps taking candidates until one needs a sweep or the work is gone
+                while (st[hf] == HF_EMPTY && (chain[hf] || !drained)) {
+                    if (!chain[hf]) {
+                        if (loc == loc_end) {
+                            uint32_t base = 0;
+                            if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
+                            base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
+                            loc = min(base, n_work);
+                            loc_end = min(base + 4, n_work);
+                        }
+                        if (loc == loc_end) {
+                            drained = true;
+                            break;
+                        }
+                        g[hf] = a.worklist[loc++];
+                        const uint32_t rs = a.cand_rs[g[hf]];
+                        const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
+                        o[hf] = a.strand_off[rs];
+                        const uint32_t b0 = a.read_off[r_];
+                        L[hf] = a.read_off[r_ + 1] - b0;
+                        const uint32_t ED = (uint32_t)ceil((double)L[hf] * a.edit_rate);  // index.rs:281-282
+                        const bool wrapped = 2ull * ED > (uint64_t)L[hf];                  // usize wrap of index.rs:406
+                        thr[hf] = L[hf] - 2 * ED;
+                        const uint8_t* read = a.bases + b0;
+                        const int pad = (int)(GS * R) - (int)L[hf];
+                        int nn = 0;
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const int p = (int)(gl * R + r) - pad;  // read position of this row, < 0 for padding
+                            const uint32_t code = p >= 0 ? strand_code(read, L[hf], strand, (uint32_t)p) : 6u;
+                            nn += code == kCodeN;
+                            qc2[r] = hf ? ((qc2[r] & 0x0000ffffu) | (code << 17)) : ((qc2[r] & 0xffff0000u) | (code << 1));
+                        }
+#pragma unroll
+                        for (int d = 1; d < GS; d <<= 1) nn += __shfl_xor(nn, d);
+                        // more N in the read than the edit tolerance: index.rs:410 fails whatever the prefilter says
+                        hopeless[hf] = wrapped || (uint32_t)nn > ED;
+                    }
+                    chain[hf] = false;
+                    const uint4 c = a.cand[g[hf]];
+                    verified++;
+                    wbytes += c.y - c.x;
+                    if (hopeless[hf]) {  // rejected without a sweep; the reference still ran its prefilter on it
+                        if (gl == 0) a.cand_status[g[hf]] = 1;
+                        const uint32_t nxt = a.cand_next[g[hf]];
+                        if (nxt != 0xffffffffu && nxt < maxc) {
+                            g[hf] = o[hf] + nxt;
+                            chain[hf] = true;
+                        }
+                    } else {
+                        wstart[hf] = c.x;
+                        Wn[hf] = c.y - c.x;
+                        st[hf] = HF_SWEEP;
+                    }
+                }
+            }
+            if (st[0] == HF_SWEEP || st[1] == HF_SWEEP) {
+                uint8_t* rings = &ring_all[threadIdx.x / GS][0][0];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    if (st[hf] != HF_SWEEP) Wn[hf] = 0;
+                    const uint32_t lim = min(Wn[hf], kRing);
+                    for (uint32_t base = 0; base < lim; base += 16 * GS) {  // 16 symbols per lane per pass
+                        const uint32_t col = base + gl * 16;
+                        if (col < lim) *reinterpret_cast<uint4*>(rings + hf * kRing + col) = load16(ix.text, ix.n, wstart[hf] + col);
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) h[r] = 0;
+                up_prev = 0;
+                best = 0;
+                t = 0;
+                steps = max(Wn[0], Wn[1]) + GS - 1;
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const uint32_t j1 = (0u - gl);
+                    cn[hf] = ((int)j1 >= 0 && j1 < Wn[hf]) ? rings[hf * kRing + (j1 & (kRing - 1))] : 7u;
+                }
+                phase = PH_SWEEP;
+            } else {
+                phase = PH_DONE;
+            }
+        }
+        if (__all(phase == PH_DONE)) break;
+        bool finish = false;
+        if (phase == PH_SWEEP) {
+            uint8_t* rings = &ring_all[threadIdx.x / GS][0][0];
+            // windows longer than the ring: see k_evaluate
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                if (Wn[hf] > kRing && t >= kRing / 2 + GS && ((t - GS) & (kRing / 2 - 1)) == 0) {
+                    const uint32_t from = (t - GS) + kRing / 2, to = min(Wn[hf], from + kRing / 2);
+                    for (uint32_t col = from + gl; col < to; col += GS) {
+                        uint32_t pos = wstart[hf] + col;
+                        rings[hf * kRing + (col & (kRing - 1))] = pos < ix.n ? ix.text[pos] : (uint8_t)7;
+                    }
+                }
+            }
+            // Decision point every 32 steps (bounds as in k_evaluate): a half passes as soon as its
+            // maximum reaches the threshold and fails as soon as no alignment through unswept cells can.
+            if ((t & 31) == 0 && t >= 32) {
+                int bmax[2], ub[2];
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    const int W_ = (int)Wn[hf], L_ = (int)L[hf];
+                    const int jl = (int)t - 1 - (int)gl;
+                    const int jc = min(jl, W_ - 1);
+                    const int cols_left = W_ - 1 - jc;
+                    const int pad = (int)(GS * R) - L_;
+                    int u = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int p = (int)(gl * R + r) - pad;
+                        const int hv = (int)((h[r] >> (16 * hf)) & 0xffffu);
+                        const int s1 = hv + 2 + min(L_ - 1 - p, cols_left);
+                        u = max(u, p >= 0 ? s1 : 0);
+                    }
+                    bmax[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;  // best tracks H + 1
+                    ub[hf] = u;
+                }
+#pragma unroll
+                for (int d = 1; d < GS; d <<= 1) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        bmax[hf] = max(bmax[hf], __shfl_xor(bmax[hf], d));
+                        ub[hf] = max(ub[hf], __shfl_xor(ub[hf], d));
+                    }
+                }
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    if (st[hf] == HF_SWEEP) {
+                        const int u = max(max(ub[hf], bmax[hf]), (int)Wn[hf] - (int)t + GS);  // or starts in unswept columns
+                        if (bmax[hf] >= (int)thr[hf]) st[hf] = HF_PASS;
+                        else if (u < (int)thr[hf] || t >= Wn[hf] + GS - 1) st[hf] = HF_FAIL;
+                    }
+                }
+                finish = st[0] != HF_SWEEP && st[1] != HF_SWEEP;
+            }
+            if (!finish) {
+#pragma unroll
+                for (int rep = 0; rep < 2; rep++) {  // two columns per trip of the phase loop
+                    const uint32_t cp2 = (cn[0] | (cn[1] << 16)) << 1;
+                    const int j1 = (int)t - (int)gl + 1;  // the column after this one
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++)
+                        cn[hf] = (j1 >= 0 && (uint32_t)j1 < Wn[hf]) ? rings[hf * kRing + ((uint32_t)j1 & (kRing - 1))] : 7u;
+                    const uint32_t in = (uint32_t)row_shr1((int)h[R - 1]);  // lane 0 of the group reads 0: H = 0
+                    uint32_t diag = up_prev, up = in;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const uint32_t e2 = pku_satsub(TWO, qc2[r] ^ cp2);  // 2 where the codes are equal, else 0
+                        const uint32_t x = pku_add(diag, e2);
+                        const uint32_t w = pku_max(pku_max(x, pku_max(up, h[r])), ONE);
+                        best = pku_max(best, w);
+                        diag = h[r];
+                        h[r] = pku_sub(w, ONE);
+                        up = h[r];
+                    }
+                    up_prev = in;
+                    t++;
+                }
+                finish = t >= steps;
+            }
+        }
+        uint32_t passed[2] = {0xffffffffu, 0xffffffffu};
+        if (phase == PH_SWEEP && finish) {
+            int bm[2];
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) bm[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;
+#pragma unroll
+            for (int d = 1; d < GS; d <<= 1) {
+                bm[0] = max(bm[0], __shfl_xor(bm[0], d));
+                bm[1] = max(bm[1], __shfl_xor(bm[1], d));
+            }
+#pragma unroll
+            for (int hf = 0; hf < 2; hf++) {
+                if (st[hf] == HF_SWEEP) st[hf] = bm[hf] >= (int)thr[hf] ? HF_PASS : HF_FAIL;
+                if (st[hf] == HF_PASS) {
+                    if (gl == 0) passed[hf] = g[hf];
+                } else if (st[hf] == HF_FAIL) {
+                    if (gl == 0) a.cand_status[g[hf]] = 1;
+                    const uint32_t nxt = a.cand_next[g[hf]];  // next candidate of this TaxId in rank order (index.rs:393)
+                    if (nxt != 0xffffffffu && nxt < maxc) {
+                        g[hf] = o[hf] + nxt;
+                        chain[hf] = true;
+                    }
+                }
+                st[hf] = HF_EMPTY;
+            }
+            phase = PH_FETCH;
+        }
+        // wave-uniform from here: collect the passed candidates of this trip
+#pragma unroll
+        for (int hf = 0; hf < 2; hf++) {
+            const unsigned long long em = __ballot(passed[hf] != 0xffffffffu);
+            if (em) {
+                const uint32_t m = __popcll(em);
+                if (pend + m > kWave) {
+                    uint32_t base = 0;
+                    if (lane == 0) base = atomicAdd(a.pass_count, pend);
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (lane < pend) a.pass_list[base + lane] = pend_buf[lane];
+                    pend = 0;
+                }
+                if (passed[hf] != 0xffffffffu) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = passed[hf];
+                pend += m;
+            }
+        }
+    }
+    if (pend) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.pass_count, pend);
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (lane < pend) a.pass_list[base + lane] = pend_buf[lane];
+    }
+    if (gl != 0) {
+        verified = 0;
+        wbytes = 0;
+    }
+    for (int d = 32; d > 0; d >>= 1) {
+        verified += __shfl_down(verified, d);
+        wbytes += __shfl_down(wbytes, d);
+    }
+    if (lane == 0 && verified) {
+        atomicAdd(a.n_verified, verified);
+        atomicAdd(a.window_bytes, wbytes);
+    }
+}
+
 // 16 window columns of a candidate in the order the sweep consumes them, as codes clamped to 0..4
 // (4 = matches nothing).  Forward strand: text[start+j0 ..]; reverse strand: text[end-1-j0], downwards
 // (complementing is folded into the match table).  Columns past the window are don't-cares.
@@ -1264,7 +1553,9 @@ __device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint3
 // the last row) with Myers' bit-vector recurrence, one lane per candidate, W 32-bit words per
 // column, match masks in LDS.  Read 'N' matches nothing (index.rs:272-279), reference 'N' matches nothing either.
 // ---------------------------------------------------------------------------------------------
-template <int W>  // W 32-bit words per column: reads of up to 32*W bases
+// LIST: the items are single candidates that already passed the SW prefilter (k_sw_pairs); one that
+// fails index.rs:410 hands its TaxId's next candidate to the next round instead of walking on.
+template <int W, bool LIST>  // W 32-bit words per column: reads of up to 32*W bases
 __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a) {
     // match masks of the lane's read, one row per window symbol (A C G T, other), word-major so that a
     // lane's reads are conflict-free whatever row it picks.  The read sits at the TOP of the 32*W rows
@@ -1364,7 +1655,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             if (exhausted) break;
             continue;
         }
-        if (active && hopeless) {  // no sweep needed: every candidate of this strand fails
+        if (!LIST && active && hopeless) {  // no sweep needed: every candidate of this strand fails
             const uint4 c = a.cand[g];
             verified++;
             wbytes += c.y - c.x;
@@ -1418,8 +1709,10 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     }
                 }
             }
-            verified++;
-            wbytes += Wn;
+            if (!LIST) {
+                verified++;
+                wbytes += Wn;
+            }
             const uint32_t ed = (uint32_t)best;
             const bool pass = !thr_wrapped && ed <= ED;
             if (pass) {
@@ -1430,7 +1723,10 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                 a.cand_status[g] = 1;
                 const uint32_t nxt = a.cand_next[g];
                 if (nxt == 0xffffffffu || nxt >= maxc) active = false;
-                else g = o + nxt;
+                else if (LIST) {  // rare: passed the prefilter, failed the edit distance
+                    a.next_list[atomicAdd(a.next_count, 1u)] = o + nxt;
+                    active = false;
+                } else g = o + nxt;
             }
         }
     }
@@ -1598,10 +1894,29 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
 #undef EVAL_CASE
 }
 
-void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
+void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
+    // persistent 16-lane groups, two candidates per group: one resident generation of blocks pulls the worklist
+#define SW_CASE(RR)                                                                                                      \
+    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 2 : 4)))), \
+                       dim3(256), 0, s, ix, a)
+    if (max_len <= 64) SW_CASE(4);
+    else if (max_len <= 96) SW_CASE(6);
+    else if (max_len <= 128) SW_CASE(8);
+    else if (max_len <= 160) SW_CASE(10);
+    else if (max_len <= 208) SW_CASE(13);
+    else SW_CASE(16);
+#undef SW_CASE
+}
+
+void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
+                       bool list_mode) {
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256), 256 * 8));
     uint32_t W = (max_len + 31) / 32;
-#define MYERS_CASE(WW) hipLaunchKernelGGL(k_edit_myers<WW>, dim3(blocks), dim3(256), 0, s, ix, a)
+#define MYERS_CASE(WW)                                                                                   \
+    do {                                                                                                 \
+        if (list_mode) hipLaunchKernelGGL((k_edit_myers<WW, true>), dim3(blocks), dim3(256), 0, s, ix, a);  \
+        else hipLaunchKernelGGL((k_edit_myers<WW, false>), dim3(blocks), dim3(256), 0, s, ix, a);           \
+    } while (0)
     if (W <= 2) MYERS_CASE(2);
     else if (W <= 3) MYERS_CASE(3);
     else if (W <= 4) MYERS_CASE(4);

@@ -34,6 +34,13 @@ struct EvalArgs {
     uint4* out;                   // out[candidate] = (tax_id, gi, offset, edit) when it passed
     unsigned long long* n_verified;
     unsigned long long* window_bytes;
+    // reference order, reads <= 253 bases: k_sw_pairs appends candidates that pass the prefilter to
+    // pass_list; k_edit_myers (list mode) verifies them and appends the successors of those that fail
+    // the edit distance to next_list, the worklist of the next round
+    uint32_t* pass_list = nullptr;
+    uint32_t* pass_count = nullptr;
+    uint32_t* next_list = nullptr;
+    uint32_t* next_count = nullptr;
 };
 
 constexpr uint32_t kMaxReadLen = 512;  // 16 lanes x 32 read rows per lane in k_evaluate
@@ -59,7 +66,10 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                      uint32_t* heavy_count, unsigned long long* n_cand_total);
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
 // edit-first order (reads up to 253 bases): Myers bit-vector edit distance, lane per candidate
-void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
+void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
+                       bool list_mode = false);
+// reference order for reads <= 253 bases: SW prefilter alone, two candidates per 16-lane group
+void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
 void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,
                     const uint32_t* strand_off, const uint32_t* strand_ncand, const uint32_t* cand_status, uint4* out,
                     uint32_t* strand_nout);
