@@ -1247,11 +1247,30 @@ __device__ inline uint32_t pku_satsub(uint32_t a, uint32_t b) { return as_bits(_
 
 enum : uint32_t { HF_EMPTY = 0, HF_SWEEP = 1, HF_PASS = 2, HF_FAIL = 3 };
 
+__device__ inline int row_sum16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
+    return v;
+}
+// maximum over the 16 lanes of a DPP row, result in every lane: quad swaps, then the two mirrors
+__device__ inline int row_max16(int v) {
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x4E, 0xf, 0xf, false));   // quad_perm [2,3,0,1]
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x141, 0xf, 0xf, false));  // row_half_mirror
+    v = max(v, __builtin_amdgcn_update_dpp(v, v, 0x140, 0xf, 0xf, false));  // row_mirror
+    return v;
+}
+
+constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
+
 template <int R>
 __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     constexpr int GS = 16;
-    __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRing];
+    __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
     __shared__ uint32_t pend_all[256 / kWave][kWave + 8];  // passed candidates, flushed with one atomic per ~64
+    __shared__ uint32_t meta_all[256 / GS][4][8];         // the group's claimed work items, staged by lanes 0..3
     const uint32_t lane = lane_id();
     const uint32_t gl = lane & (GS - 1);
     uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
@@ -1262,7 +1281,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
     const uint32_t ONE = 0x00010001u, TWO = 0x00020002u;
 
     uint32_t phase = PH_FETCH;
-    uint32_t loc = 0, loc_end = 0;
+    uint32_t loc = 0, loc_end = 0, slice0 = 0;
     bool drained = false;
     // per-half state; index 0 = low half
     uint32_t st[2] = {HF_EMPTY, HF_EMPTY};
@@ -1281,50 +1300,116 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
 
     for (;;) {
         if (phase == PH_FETCH) {
+            uint8_t* rings = &ring_all[threadIdx.x / GS][0][0];
+            uint32_t* meta = &meta_all[threadIdx.x / GS][0][0];
+            // Two passes so that the global loads of both halves are in flight together: pass 1 picks the
+            // candidates and issues the loads (window text, read bytes), pass 2 consumes them.  Repeats
+            // only when a freshly loaded read turns out to hold more N than the edit tolerance.
+            for (;;) {
+                bool want[2] = {false, false}, fresh[2] = {false, false};
+                uint32_t cx[2] = {0, 0}, cy[2] = {0, 0}, b0s[2] = {0, 0}, strands[2] = {0, 0};
+                uint4 txt[2];
+                constexpr int RW = (R + 3) / 4;  // dwords that hold a lane's R read bytes
+                uint32_t raw[2][RW];
 #pragma unroll
-            for (int hf = 0; hf < 2; hf++) {
-                // a half keeps taking candidates until one needs a sweep or the work is gone
-                while (st[hf] == HF_EMPTY && (chain[hf] || !drained)) {
-                    if (!chain[hf]) {
+                for (int hf = 0; hf < 2; hf++) {
+                    txt[hf] = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
+                    if (st[hf] != HF_EMPTY) continue;
+                    if (chain[hf]) {  // next candidate of the same TaxId: same read rows, new window
+                        const uint4 c = a.cand[g[hf]];
+                        cx[hf] = c.x;
+                        cy[hf] = c.y;
+                        chain[hf] = false;
+                        want[hf] = true;
+                    } else if (!drained) {
                         if (loc == loc_end) {
                             uint32_t base = 0;
                             if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
                             base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
                             loc = min(base, n_work);
                             loc_end = min(base + 4, n_work);
+                            slice0 = loc;
+                            // lanes 0..3 of the group walk the dependent loads of one item each, side by side
+                            if (gl < 4 && loc + gl < loc_end) {
+                                const uint32_t gi = a.worklist[loc + gl];
+                                const uint32_t rs = a.cand_rs[gi];
+                                const uint4 c = a.cand[gi];
+                                const uint32_t r_ = a.r0 + (rs >> 1);
+                                const uint32_t b0 = a.read_off[r_];
+                                uint32_t* m = meta + gl * 8;
+                                m[0] = gi;
+                                m[1] = c.x;
+                                m[2] = c.y;
+                                m[3] = a.strand_off[rs];
+                                m[4] = b0;
+                                m[5] = a.read_off[r_ + 1] - b0;
+                                m[6] = rs & 1;
+                            }
                         }
                         if (loc == loc_end) {
                             drained = true;
-                            break;
+                        } else {
+                            const uint32_t* m = meta + (loc - slice0) * 8;
+                            loc++;
+                            g[hf] = m[0];
+                            cx[hf] = m[1];
+                            cy[hf] = m[2];
+                            o[hf] = m[3];
+                            b0s[hf] = m[4];
+                            L[hf] = m[5];
+                            strands[hf] = m[6];
+                            fresh[hf] = true;
+                            want[hf] = true;
                         }
-                        g[hf] = a.worklist[loc++];
-                        const uint32_t rs = a.cand_rs[g[hf]];
-                        const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
-                        o[hf] = a.strand_off[rs];
-                        const uint32_t b0 = a.read_off[r_];
-                        L[hf] = a.read_off[r_ + 1] - b0;
+                    }
+                    if (want[hf]) {
+                        if (gl * 16 < cy[hf] - cx[hf]) txt[hf] = load16(ix.text, ix.n, cx[hf] + gl * 16);
+                        if (fresh[hf]) {
+                            // the lane's rows are R consecutive read bytes (descending for the reverse strand):
+                            // aligned dword loads + v_alignbyte; byte k of raw[] is read byte s0 + k
+                            const int pad = (int)(GS * R) - (int)L[hf];
+                            const int p0 = (int)(gl * R) - pad;  // read position of row 0, < 0 for padding rows
+                            const int s0 = strands[hf] ? (int)L[hf] - 1 - p0 - (R - 1) : p0;
+                            const long long byte0 = (long long)b0s[hf] + s0;
+                            const long long w0 = byte0 >> 2;
+                            const uint32_t sh = (uint32_t)(byte0 & 3);
+                            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(a.bases);
+                            uint32_t d[RW + 1];
+#pragma unroll
+                            for (int k = 0; k <= RW; k++) d[k] = w0 + k >= 0 ? b32[w0 + k] : 0u;
+#pragma unroll
+                            for (int k = 0; k < RW; k++) raw[hf][k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+                        }
+                    }
+                }
+                bool again = false;
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) {
+                    if (!want[hf]) continue;
+                    if (fresh[hf]) {
                         const uint32_t ED = (uint32_t)ceil((double)L[hf] * a.edit_rate);  // index.rs:281-282
                         const bool wrapped = 2ull * ED > (uint64_t)L[hf];                  // usize wrap of index.rs:406
                         thr[hf] = L[hf] - 2 * ED;
-                        const uint8_t* read = a.bases + b0;
                         const int pad = (int)(GS * R) - (int)L[hf];
                         int nn = 0;
 #pragma unroll
                         for (int r = 0; r < R; r++) {
-                            const int p = (int)(gl * R + r) - pad;  // read position of this row, < 0 for padding
-                            const uint32_t code = p >= 0 ? strand_code(read, L[hf], strand, (uint32_t)p) : 6u;
+                            const int p = (int)(gl * R + r) - pad;
+                            const uint32_t kf = (uint32_t)r, kr = (uint32_t)(R - 1 - r);  // byte of this row in raw[]
+                            const uint32_t bf = (raw[hf][kf >> 2] >> (8 * (kf & 3))) & 0xffu;
+                            const uint32_t br = (raw[hf][kr >> 2] >> (8 * (kr & 3))) & 0xffu;
+                            uint32_t code = fast_code(strands[hf] ? br : bf);
+                            if (strands[hf]) code = comp_code(code);
+                            if (p < 0) code = 6u;
                             nn += code == kCodeN;
                             qc2[r] = hf ? ((qc2[r] & 0x0000ffffu) | (code << 17)) : ((qc2[r] & 0xffff0000u) | (code << 1));
                         }
-#pragma unroll
-                        for (int d = 1; d < GS; d <<= 1) nn += __shfl_xor(nn, d);
+                        nn = row_sum16(nn);
                         // more N in the read than the edit tolerance: index.rs:410 fails whatever the prefilter says
                         hopeless[hf] = wrapped || (uint32_t)nn > ED;
                     }
-                    chain[hf] = false;
-                    const uint4 c = a.cand[g[hf]];
                     verified++;
-                    wbytes += c.y - c.x;
+                    wbytes += cy[hf] - cx[hf];
                     if (hopeless[hf]) {  // rejected without a sweep; the reference still ran its prefilter on it
                         if (gl == 0) a.cand_status[g[hf]] = 1;
                         const uint32_t nxt = a.cand_next[g[hf]];
@@ -1332,24 +1417,25 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
                             g[hf] = o[hf] + nxt;
                             chain[hf] = true;
                         }
+                        again = again || chain[hf] || !drained;
                     } else {
-                        wstart[hf] = c.x;
-                        Wn[hf] = c.y - c.x;
+                        wstart[hf] = cx[hf];
+                        Wn[hf] = cy[hf] - cx[hf];
                         st[hf] = HF_SWEEP;
+                        const uint32_t lim = min(Wn[hf], kRingP);
+                        if (gl * 16 < lim) *reinterpret_cast<uint4*>(rings + hf * kRingP + gl * 16) = txt[hf];
+                        for (uint32_t base = 16 * GS; base < lim; base += 16 * GS) {  // windows beyond 256 symbols
+                            const uint32_t col = base + gl * 16;
+                            if (col < lim) *reinterpret_cast<uint4*>(rings + hf * kRingP + col) = load16(ix.text, ix.n, wstart[hf] + col);
+                        }
                     }
                 }
+                if (!again) break;
             }
             if (st[0] == HF_SWEEP || st[1] == HF_SWEEP) {
-                uint8_t* rings = &ring_all[threadIdx.x / GS][0][0];
 #pragma unroll
-                for (int hf = 0; hf < 2; hf++) {
+                for (int hf = 0; hf < 2; hf++)
                     if (st[hf] != HF_SWEEP) Wn[hf] = 0;
-                    const uint32_t lim = min(Wn[hf], kRing);
-                    for (uint32_t base = 0; base < lim; base += 16 * GS) {  // 16 symbols per lane per pass
-                        const uint32_t col = base + gl * 16;
-                        if (col < lim) *reinterpret_cast<uint4*>(rings + hf * kRing + col) = load16(ix.text, ix.n, wstart[hf] + col);
-                    }
-                }
 #pragma unroll
                 for (int r = 0; r < R; r++) h[r] = 0;
                 up_prev = 0;
@@ -1359,7 +1445,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
                     const uint32_t j1 = (0u - gl);
-                    cn[hf] = ((int)j1 >= 0 && j1 < Wn[hf]) ? rings[hf * kRing + (j1 & (kRing - 1))] : 7u;
+                    cn[hf] = ((int)j1 >= 0 && j1 < Wn[hf]) ? rings[hf * kRingP + (j1 & (kRingP - 1))] : 7u;
                 }
                 phase = PH_SWEEP;
             } else {
@@ -1373,11 +1459,11 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
             // windows longer than the ring: see k_evaluate
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
-                if (Wn[hf] > kRing && t >= kRing / 2 + GS && ((t - GS) & (kRing / 2 - 1)) == 0) {
-                    const uint32_t from = (t - GS) + kRing / 2, to = min(Wn[hf], from + kRing / 2);
+                if (Wn[hf] > kRingP && t >= kRingP / 2 + GS && ((t - GS) & (kRingP / 2 - 1)) == 0) {
+                    const uint32_t from = (t - GS) + kRingP / 2, to = min(Wn[hf], from + kRingP / 2);
                     for (uint32_t col = from + gl; col < to; col += GS) {
                         uint32_t pos = wstart[hf] + col;
-                        rings[hf * kRing + (col & (kRing - 1))] = pos < ix.n ? ix.text[pos] : (uint8_t)7;
+                        rings[hf * kRingP + (col & (kRingP - 1))] = pos < ix.n ? ix.text[pos] : (uint8_t)7;
                     }
                 }
             }
@@ -1404,12 +1490,9 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
                     ub[hf] = u;
                 }
 #pragma unroll
-                for (int d = 1; d < GS; d <<= 1) {
-#pragma unroll
-                    for (int hf = 0; hf < 2; hf++) {
-                        bmax[hf] = max(bmax[hf], __shfl_xor(bmax[hf], d));
-                        ub[hf] = max(ub[hf], __shfl_xor(ub[hf], d));
-                    }
+                for (int hf = 0; hf < 2; hf++) {
+                    bmax[hf] = row_max16(bmax[hf]);
+                    ub[hf] = row_max16(ub[hf]);
                 }
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
@@ -1427,18 +1510,29 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
                     const uint32_t cp2 = (cn[0] | (cn[1] << 16)) << 1;
                     const int j1 = (int)t - (int)gl + 1;  // the column after this one
 #pragma unroll
-                    for (int hf = 0; hf < 2; hf++)
-                        cn[hf] = (j1 >= 0 && (uint32_t)j1 < Wn[hf]) ? rings[hf * kRing + ((uint32_t)j1 & (kRing - 1))] : 7u;
+                    for (int hf = 0; hf < 2; hf++) {  // unconditional LDS read (the index is masked), then a select
+                        const uint32_t sym = rings[hf * kRingP + ((uint32_t)j1 & (kRingP - 1))];
+                        cn[hf] = (uint32_t)j1 < Wn[hf] ? sym : 7u;  // j1 < 0 wraps to a huge unsigned value
+                    }
                     const uint32_t in = (uint32_t)row_shr1((int)h[R - 1]);  // lane 0 of the group reads 0: H = 0
-                    uint32_t diag = up_prev, up = in;
+                    // off the dependent chain: T[r] = max(diag + 2*[match], left) from the previous column
+                    uint32_t T[R];
+                    {
+                        uint32_t diag = up_prev;
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const uint32_t e2 = pku_satsub(TWO, qc2[r] ^ cp2);  // 2 where the codes are equal, else 0
+                            T[r] = pku_max(pku_add(diag, e2), h[r]);
+                            diag = h[r];
+                        }
+                    }
+                    // the chain down the rows: H + 1 = max(T, up, 1), two dependent operations per row
+                    uint32_t up = in;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
-                        const uint32_t e2 = pku_satsub(TWO, qc2[r] ^ cp2);  // 2 where the codes are equal, else 0
-                        const uint32_t x = pku_add(diag, e2);
-                        const uint32_t w = pku_max(pku_max(x, pku_max(up, h[r])), ONE);
+                        const uint32_t w = pku_max(T[r], up);
                         best = pku_max(best, w);
-                        diag = h[r];
-                        h[r] = pku_sub(w, ONE);
+                        h[r] = pku_satsub(w, ONE);  // max(w, 1) - 1
                         up = h[r];
                     }
                     up_prev = in;
@@ -1452,11 +1546,8 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
             int bm[2];
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) bm[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;
-#pragma unroll
-            for (int d = 1; d < GS; d <<= 1) {
-                bm[0] = max(bm[0], __shfl_xor(bm[0], d));
-                bm[1] = max(bm[1], __shfl_xor(bm[1], d));
-            }
+            bm[0] = row_max16(bm[0]);
+            bm[1] = row_max16(bm[1]);
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
                 if (st[hf] == HF_SWEEP) st[hf] = bm[hf] >= (int)thr[hf] ? HF_PASS : HF_FAIL;
@@ -1897,7 +1988,7 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
 void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
     // persistent 16-lane groups, two candidates per group: one resident generation of blocks pulls the worklist
 #define SW_CASE(RR)                                                                                                      \
-    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 2 : 4)))), \
+    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 2 : 5)))), \
                        dim3(256), 0, s, ix, a)
     if (max_len <= 64) SW_CASE(4);
     else if (max_len <= 96) SW_CASE(6);
