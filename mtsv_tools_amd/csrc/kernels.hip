@@ -1264,9 +1264,13 @@ __device__ inline int row_max16(int v) {
 }
 
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
+#ifndef MTSV_DECIDE
+#define MTSV_DECIDE 32
+#endif
+constexpr uint32_t kDecide = MTSV_DECIDE;  // columns between decision points
 
 template <int R>
-__global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
+__global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     constexpr int GS = 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
     __shared__ uint32_t pend_all[256 / kWave][kWave + 8];  // passed candidates, flushed with one atomic per ~64
@@ -1299,7 +1303,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
     }
 
     for (;;) {
-        if (phase == PH_FETCH) {
+        if (__builtin_expect(phase == PH_FETCH, 0)) {
             uint8_t* rings = &ring_all[threadIdx.x / GS][0][0];
             uint32_t* meta = &meta_all[threadIdx.x / GS][0][0];
             // Two passes so that the global loads of both halves are in flight together: pass 1 picks the
@@ -1469,8 +1473,13 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
             }
             // Decision point every 32 steps (bounds as in k_evaluate): a half passes as soon as its
             // maximum reaches the threshold and fails as soon as no alignment through unswept cells can.
-            if ((t & 31) == 0 && t >= 32) {
+            if (__builtin_expect((t & (kDecide - 1)) == 0 && t >= 32, 0)) {
                 int bmax[2], ub[2];
+                // one bound per lane instead of one per row: the lane's largest H with the row count of
+                // its first real row (at most R - 1 looser than the per-row bound of k_evaluate)
+                uint32_t hm = h[0];
+#pragma unroll
+                for (int r = 1; r < R; r++) hm = pku_max(hm, h[r]);
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
                     const int W_ = (int)Wn[hf], L_ = (int)L[hf];
@@ -1478,16 +1487,10 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
                     const int jc = min(jl, W_ - 1);
                     const int cols_left = W_ - 1 - jc;
                     const int pad = (int)(GS * R) - L_;
-                    int u = 0;
-#pragma unroll
-                    for (int r = 0; r < R; r++) {
-                        const int p = (int)(gl * R + r) - pad;
-                        const int hv = (int)((h[r] >> (16 * hf)) & 0xffffu);
-                        const int s1 = hv + 2 + min(L_ - 1 - p, cols_left);
-                        u = max(u, p >= 0 ? s1 : 0);
-                    }
+                    const int p_first = max((int)(gl * R) - pad, 0), p_last = (int)(gl * R + R - 1) - pad;
+                    const int hv = (int)((hm >> (16 * hf)) & 0xffffu);
+                    ub[hf] = p_last >= 0 ? hv + 2 + min(L_ - 1 - p_first, cols_left) : 0;
                     bmax[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;  // best tracks H + 1
-                    ub[hf] = u;
                 }
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
@@ -1542,7 +1545,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 4) void k_sw_pairs(DevIndexView i
             }
         }
         uint32_t passed[2] = {0xffffffffu, 0xffffffffu};
-        if (phase == PH_SWEEP && finish) {
+        if (__builtin_expect(phase == PH_SWEEP && finish, 0)) {
             int bm[2];
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) bm[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;
