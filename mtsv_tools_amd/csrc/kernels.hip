@@ -1264,10 +1264,7 @@ __device__ inline int row_max16(int v) {
 }
 
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
-#ifndef MTSV_DECIDE
-#define MTSV_DECIDE 32
-#endif
-constexpr uint32_t kDecide = MTSV_DECIDE;  // columns between decision points
+constexpr uint32_t kDecide = 32;  // columns between decision points after the two scheduled ones
 
 template <int R>
 __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
@@ -1294,7 +1291,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
     uint32_t qc2[R];  // read codes << 1, both halves
     uint32_t h[R], up_prev = 0, best = 0;
     uint32_t cn[2] = {14, 14};
-    uint32_t t = 0, steps = 0;
+    uint32_t t = 0, steps = 0, next_check = 0, second_check = 0;
     unsigned long long verified = 0, wbytes = 0;
 #pragma unroll
     for (int r = 0; r < R; r++) {
@@ -1446,6 +1443,22 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                 best = 0;
                 t = 0;
                 steps = max(Wn[0], Wn[1]) + GS - 1;
+                // Decision points: the first where a window without a real alignment typically runs out of
+                // columns (Wn - thr columns swept, plus the lane skew and the score such a window reaches
+                // by chance), the second where a true alignment typically reaches the threshold (its
+                // start offset ~(Wn - L)/2, thr rows further down, in lane thr/R), then every kDecide.
+                {
+                    uint32_t tj = 0, tt = 0;
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) {
+                        if (st[hf] != HF_SWEEP) continue;
+                        const uint32_t slack = Wn[hf] > L[hf] ? (Wn[hf] - L[hf]) / 2 : 0;
+                        tj = max(tj, (Wn[hf] > thr[hf] ? Wn[hf] - thr[hf] : 0) + GS + 12);
+                        tt = max(tt, slack + thr[hf] + thr[hf] / R + 10);
+                    }
+                    next_check = max(32u, (tj + 1) & ~1u);
+                    second_check = (tt + 1) & ~1u;
+                }
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
                     const uint32_t j1 = (0u - gl);
@@ -1473,7 +1486,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
             }
             // Decision point every 32 steps (bounds as in k_evaluate): a half passes as soon as its
             // maximum reaches the threshold and fails as soon as no alignment through unswept cells can.
-            if (__builtin_expect((t & (kDecide - 1)) == 0 && t >= 32, 0)) {
+            if (__builtin_expect(t >= next_check, 0)) {
                 int bmax[2], ub[2];
                 // one bound per lane instead of one per row: the lane's largest H with the row count of
                 // its first real row (at most R - 1 looser than the per-row bound of k_evaluate)
@@ -1506,6 +1519,8 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                     }
                 }
                 finish = st[0] != HF_SWEEP && st[1] != HF_SWEEP;
+                next_check = second_check > t + 8 ? second_check : t + kDecide;
+                second_check = 0;
             }
             if (!finish) {
 #pragma unroll
