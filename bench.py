@@ -60,6 +60,8 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle")
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (the box's CPU share of one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the PCIe-inclusive leg and the other verify order (profiling runs: only the timed passes launch kernels)")
     ap.add_argument("--verify-mode", type=int, default=0, help="0: reference order (SW + edit per candidate), 1: edit first")
     ap.add_argument("--dev-flags", type=int, default=0, help="MTSV_DEV_* flags (1: sampled SA only, 2: no k-mer table)")
     args = ap.parse_args()
@@ -169,7 +171,8 @@ def main():
     t0 = time.time()
     # host buffers in, host hits out (what mtsv_bin_batch does): 1 Mi-read slices, copy of slice k+1
     # overlapped with the kernels of slice k
-    batch_pcie = M.Batch(ix, local_rank, min(n_reads, 1 << 20), min(len(bases), (1 << 20) * (read_len + 8))) if rank == 0 else None
+    batch_pcie = (M.Batch(ix, local_rank, min(n_reads, 1 << 20), min(len(bases), (1 << 20) * (read_len + 8)))
+                  if rank == 0 and not args.no_extras else None)
     pcie_rate = None
     if batch_pcie is not None:
         batch_pcie.set_verify_mode(args.verify_mode)
@@ -188,7 +191,7 @@ def main():
         del pcie_hits
     # the other evaluation order of the two acceptance predicates, for information (never `value`)
     alt = None
-    if rank == 0:
+    if rank == 0 and not args.no_extras:
         other = 1 - args.verify_mode
         batch.set_verify_mode(other)
         batch.run(params)
@@ -241,7 +244,9 @@ def main():
     # achieved = algorithmic bytes / time against the HBM peak.  Primary figure: the whole
     # pipeline (what `value` is made of).  The per-stage table prices every kernel with its own
     # algorithmic bytes; the dominant kernel is named with its share of the step.
-    kernel_stage = {"search": "k_search", "locate": "k_locate", "verify": "k_evaluate (+k_resolve)",
+    verify_name = ("k_edit_myers (+k_resolve)" if args.verify_mode == 1 else
+                   "k_sw_pairs + k_edit_myers (+k_resolve)" if read_len <= 253 else "k_evaluate (+k_resolve)")
+    kernel_stage = {"search": "k_search", "locate": "k_locate", "verify": verify_name,
                     "coalesce": "k_coalesce", "expand": "k_expand", "thin_scan": "k_thin+scan", "gather": "scan+k_gather"}
     dom = max((k for k in stage_ms if k != "total"), key=lambda k: stage_ms[k])
     roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,

@@ -8,8 +8,10 @@
 //   k_expand    lane per kept seed: its SA rows / text positions (Interval::occ)  index.rs:347-352
 //   k_locate    lane per seed hit with wavefront refill: SampledSuffixArray::get  index.rs:347
 //   k_coalesce  wavefront per strand: sort, coalesce_seed_sites, min_seeds, rank  index.rs:358-369,435-487
-//   k_evaluate  16-lane group per candidate: SW prefilter + edit distance         index.rs:401-410,
-//               (rounds follow the same-TaxId chains of the ordered loop)         ssw.c:123-328, align.rs:28-85
+//   k_sw_pairs  16-lane group per two candidates: the SW prefilter                index.rs:401-406, ssw.c:123-328
+//   k_edit_myers  lane per candidate that passed it: bit-vector edit distance     index.rs:407-410, align.rs:28-85
+//               (rounds follow the same-TaxId chains of the ordered loop)
+//   k_evaluate  reads of 254-512 bases: both in one sweep + sw_sse2_word          ssw.c:354-530
 //   k_resolve   lane per strand: cut-offs and rank order of the selection loop    index.rs:384-428
 //   scan + k_gather  compact per-strand hits into (read, strand, rank) order      binner.rs:128
 //
@@ -1484,7 +1486,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                     }
                 }
             }
-            // Decision point every 32 steps (bounds as in k_evaluate): a half passes as soon as its
+            // Decision point (bounds as in k_evaluate): a half passes as soon as its
             // maximum reaches the threshold and fails as soon as no alignment through unswept cells can.
             if (__builtin_expect(t >= next_check, 0)) {
                 int bmax[2], ub[2];

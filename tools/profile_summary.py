@@ -1,0 +1,77 @@
+"""Summarise rocprofv3 CSV output of a `bench.py --no-extras` run into the JSON files kept under profiles/.
+
+  python tools/profile_summary.py trace  <dir with *_kernel_trace.csv>  out.csv
+      per-kernel calls / total / per-pipeline-pass duration (a pass = one k_search launch)
+  python tools/profile_summary.py pmc <dir FETCH_SIZE run> <dir WRITE_SIZE run> workload out.json traffic.json
+      per-kernel FETCH_SIZE / WRITE_SIZE sums and the per-step HBM bytes bench.py quotes as roofline.traffic
+"""
+import collections
+import csv
+import glob
+import json
+import os
+import re
+import sys
+
+
+def norm(name):
+    name = name.replace("void ", "").replace("mtsv::(anonymous namespace)::", "")
+    return re.sub(r"\(.*", "", name)
+
+
+def find(d, suffix):
+    hits = glob.glob(os.path.join(d, "**", "*" + suffix), recursive=True)
+    if not hits:
+        raise SystemExit(f"no *{suffix} under {d}")
+    return hits[0]
+
+
+def trace(d, out):
+    dur, calls = collections.defaultdict(float), collections.Counter()
+    for r in csv.DictReader(open(find(d, "kernel_trace.csv"))):
+        k = norm(r["Kernel_Name"])
+        dur[k] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+        calls[k] += 1
+    passes = max(1, calls.get("k_search", 1))
+    with open(out, "w") as f:
+        f.write("kernel,calls,total_ms,ms_per_pipeline_pass,avg_ms_per_call\n")
+        for k in sorted(dur, key=lambda k: -dur[k]):
+            in_pipeline = k.startswith("k_") and k not in ("k_expand_sa", "k_kmer_level", "k_kmer_level1")
+            f.write(f"{k},{calls[k]},{dur[k]:.3f},{dur[k] / passes if in_pipeline else float('nan'):.3f},{dur[k] / calls[k]:.4f}\n")
+    print(f"{passes} pipeline passes; wrote {out}")
+
+
+def pmc(dfetch, dwrite, workload, out, traffic):
+    per = {}
+    passes = 1
+    for name, d in (("FETCH_SIZE", dfetch), ("WRITE_SIZE", dwrite)):
+        acc, calls = collections.defaultdict(float), collections.Counter()
+        for r in csv.DictReader(open(find(d, "counter_collection.csv"))):
+            if r["Counter_Name"] != name:
+                continue
+            k = norm(r["Kernel_Name"])
+            acc[k] += float(r["Counter_Value"])
+            calls[k] += 1
+        passes = max(1, calls.get("k_search", 1))
+        per[name + "_KB"] = {k: {"sum": acc[k], "dispatches": calls[k]} for k in acc}
+    def pipeline(kind):
+        return sum(v["sum"] for k, v in per[kind].items()
+                   if k.startswith("k_") and k not in ("k_expand_sa", "k_kmer_level", "k_kmer_level1")) * 1024 / passes
+    fetch, write = pipeline("FETCH_SIZE_KB"), pipeline("WRITE_SIZE_KB")
+    summary = {
+        "workload": workload, "dev_flags": 0,
+        "source": f"{os.path.join('profiles', os.path.basename(out))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `bench.py --no-extras`; per-step = per-kernel sums / pipeline passes in the profiled process)",
+        "fetch_bytes_per_step_raw": fetch, "write_bytes_per_step": write, "hbm_bytes_per_step": fetch + write,
+        "note": "FETCH_SIZE is in KiB and, per MI355X_MICROARCH.md, under-reports wide coalesced streams by 2x on gfx950; this path's 16-B-per-lane random gathers are uncalibrated, so the raw counter is quoted (with the 2x correction: fetch*2+write)",
+        "hbm_bytes_per_step_with_2x_fetch_correction": 2 * fetch + write,
+    }
+    json.dump({"per_kernel": per, "summary": summary, "pipeline_passes_in_process": passes}, open(out, "w"), indent=1)
+    json.dump(summary, open(traffic, "w"), indent=1)
+    print(f"{passes} passes: fetch {fetch / 1e9:.1f} GB, write {write / 1e9:.1f} GB per step")
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "trace":
+        trace(sys.argv[2], sys.argv[3])
+    else:
+        pmc(*sys.argv[2:7])
