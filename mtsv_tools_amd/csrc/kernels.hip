@@ -1292,7 +1292,6 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
     bool chain[2] = {false, false}, hopeless[2] = {false, false};
     uint32_t qc2[R];  // read codes << 1, both halves
     uint32_t h[R], up_prev = 0, best = 0;
-    uint32_t cn[2] = {14, 14};
     uint32_t t = 0, steps = 0, next_check = 0, second_check = 0;
     unsigned long long verified = 0, wbytes = 0;
 #pragma unroll
@@ -1458,13 +1457,8 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                         tj = max(tj, (Wn[hf] > thr[hf] ? Wn[hf] - thr[hf] : 0) + GS + 12);
                         tt = max(tt, slack + thr[hf] + thr[hf] / R + 10);
                     }
-                    next_check = max(32u, (tj + 1) & ~1u);
-                    second_check = (tt + 1) & ~1u;
-                }
-#pragma unroll
-                for (int hf = 0; hf < 2; hf++) {
-                    const uint32_t j1 = (0u - gl);
-                    cn[hf] = ((int)j1 >= 0 && j1 < Wn[hf]) ? rings[hf * kRingP + (j1 & (kRingP - 1))] : 7u;
+                    next_check = max(32u, (tj + 3) & ~3u);
+                    second_check = (tt + 3) & ~3u;
                 }
                 phase = PH_SWEEP;
             } else {
@@ -1525,15 +1519,26 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                 second_check = 0;
             }
             if (!finish) {
+                // four columns per trip: this lane's columns j0 .. j0+3 of both windows come from the rings as two
+                // aligned dwords + v_alignbyte each; columns outside [0, Wn) read as 7 (matches nothing)
+                const int j0 = (int)t - (int)gl;
+                uint32_t four2[2];
 #pragma unroll
-                for (int rep = 0; rep < 2; rep++) {  // two columns per trip of the phase loop
-                    const uint32_t cp2 = (cn[0] | (cn[1] << 16)) << 1;
-                    const int j1 = (int)t - (int)gl + 1;  // the column after this one
+                for (int hf = 0; hf < 2; hf++) {
+                    const uint32_t* ring32 = reinterpret_cast<const uint32_t*>(rings + hf * kRingP);
+                    const int w = j0 >> 2;  // arithmetic: floor for the negative columns of the pipeline fill
+                    const uint32_t d0 = ring32[(uint32_t)w & (kRingP / 4 - 1)], d1 = ring32[(uint32_t)(w + 1) & (kRingP / 4 - 1)];
+                    const uint32_t four = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)j0 & 3u);
+                    const int lo = min(max(-j0, 0), 4), hi = min(max((int)Wn[hf] - j0, 0), 4);  // valid bytes: [lo, hi)
+                    const uint32_t mlo = lo >= 4 ? 0xffffffffu : (1u << (8 * lo)) - 1u;
+                    const uint32_t mhi = hi >= 4 ? 0xffffffffu : (1u << (8 * hi)) - 1u;
+                    const uint32_t mask = mhi & ~mlo;
+                    four2[hf] = ((four & mask) | (0x07070707u & ~mask)) << 1;  // codes << 1, no carry between bytes
+                }
 #pragma unroll
-                    for (int hf = 0; hf < 2; hf++) {  // unconditional LDS read (the index is masked), then a select
-                        const uint32_t sym = rings[hf * kRingP + ((uint32_t)j1 & (kRingP - 1))];
-                        cn[hf] = (uint32_t)j1 < Wn[hf] ? sym : 7u;  // j1 < 0 wraps to a huge unsigned value
-                    }
+                for (int rep = 0; rep < 4; rep++) {
+                    // byte `rep` of window A into the low half, of window B into the high half
+                    const uint32_t cp2 = __builtin_amdgcn_perm(four2[1], four2[0], 0x0c040c00u + (uint32_t)rep * 0x00010001u);
                     const uint32_t in = (uint32_t)row_shr1((int)h[R - 1]);  // lane 0 of the group reads 0: H = 0
                     // off the dependent chain: T[r] = max(diag + 2*[match], left) from the previous column
                     uint32_t T[R];
