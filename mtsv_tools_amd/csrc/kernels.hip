@@ -1284,16 +1284,20 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
     const uint32_t ONE = 0x00010001u, TWO = 0x00020002u;
 
     uint32_t phase = PH_FETCH;
-    uint32_t loc = 0, loc_end = 0, slice0 = 0;
+    uint32_t loc = 0, loc_end = 0;  // position inside the claimed slice of <= 4 items
     bool drained = false;
     // per-half state; index 0 = low half
     uint32_t st[2] = {HF_EMPTY, HF_EMPTY};
-    uint32_t g[2] = {0, 0}, o[2] = {0, 0}, L[2] = {0, 0}, thr[2] = {0, 0}, Wn[2] = {0, 0}, wstart[2] = {0, 0};
+    uint32_t g[2] = {0, 0}, o[2] = {0, 0}, Wn[2] = {0, 0};
+    uint32_t geo = 0;  // read length (<= 253) and SW threshold of both halves, one byte each: L0 L1 thr0 thr1
+    auto Lh = [&](int hf) { return (geo >> (8 * hf)) & 0xffu; };
+    auto thrh = [&](int hf) { return (geo >> (16 + 8 * hf)) & 0xffu; };
     bool chain[2] = {false, false}, hopeless[2] = {false, false};
     uint32_t qc2[R];  // read codes << 1, both halves
     uint32_t h[R], up_prev = 0, best = 0;
-    uint32_t t = 0, steps = 0, next_check = 0, second_check = 0;
-    unsigned long long verified = 0, wbytes = 0;
+    uint32_t t = 0, steps = 0;
+    uint32_t checks = 0;  // next decision point (low 16 bits, saturated) and the scheduled second one (high 16 bits)
+    uint32_t verified = 0, wbytes = 0;  // per group: far below 2^32 in one launch
 #pragma unroll
     for (int r = 0; r < R; r++) {
         qc2[r] = 0x000c000cu;  // code 6 << 1 in both halves: matches nothing
@@ -1328,12 +1332,12 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                             uint32_t base = 0;
                             if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
                             base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
-                            loc = min(base, n_work);
-                            loc_end = min(base + 4, n_work);
-                            slice0 = loc;
+                            const uint32_t first = min(base, n_work);
+                            loc = 0;
+                            loc_end = min(base + 4, n_work) - first;
                             // lanes 0..3 of the group walk the dependent loads of one item each, side by side
-                            if (gl < 4 && loc + gl < loc_end) {
-                                const uint32_t gi = a.worklist[loc + gl];
+                            if (gl < loc_end) {
+                                const uint32_t gi = a.worklist[first + gl];
                                 const uint32_t rs = a.cand_rs[gi];
                                 const uint4 c = a.cand[gi];
                                 const uint32_t r_ = a.r0 + (rs >> 1);
@@ -1351,14 +1355,14 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                         if (loc == loc_end) {
                             drained = true;
                         } else {
-                            const uint32_t* m = meta + (loc - slice0) * 8;
+                            const uint32_t* m = meta + loc * 8;
                             loc++;
                             g[hf] = m[0];
                             cx[hf] = m[1];
                             cy[hf] = m[2];
                             o[hf] = m[3];
                             b0s[hf] = m[4];
-                            L[hf] = m[5];
+                            geo = (geo & ~(0xffu << (8 * hf))) | ((m[5] & 0xffu) << (8 * hf));
                             strands[hf] = m[6];
                             fresh[hf] = true;
                             want[hf] = true;
@@ -1369,9 +1373,9 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                         if (fresh[hf]) {
                             // the lane's rows are R consecutive read bytes (descending for the reverse strand):
                             // aligned dword loads + v_alignbyte; byte k of raw[] is read byte s0 + k
-                            const int pad = (int)(GS * R) - (int)L[hf];
+                            const int pad = (int)(GS * R) - (int)Lh(hf);
                             const int p0 = (int)(gl * R) - pad;  // read position of row 0, < 0 for padding rows
-                            const int s0 = strands[hf] ? (int)L[hf] - 1 - p0 - (R - 1) : p0;
+                            const int s0 = strands[hf] ? (int)Lh(hf) - 1 - p0 - (R - 1) : p0;
                             const long long byte0 = (long long)b0s[hf] + s0;
                             const long long w0 = byte0 >> 2;
                             const uint32_t sh = (uint32_t)(byte0 & 3);
@@ -1389,10 +1393,10 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                 for (int hf = 0; hf < 2; hf++) {
                     if (!want[hf]) continue;
                     if (fresh[hf]) {
-                        const uint32_t ED = (uint32_t)ceil((double)L[hf] * a.edit_rate);  // index.rs:281-282
-                        const bool wrapped = 2ull * ED > (uint64_t)L[hf];                  // usize wrap of index.rs:406
-                        thr[hf] = L[hf] - 2 * ED;
-                        const int pad = (int)(GS * R) - (int)L[hf];
+                        const uint32_t ED = (uint32_t)ceil((double)Lh(hf) * a.edit_rate);  // index.rs:281-282
+                        const bool wrapped = 2ull * ED > (uint64_t)Lh(hf);                  // usize wrap of index.rs:406
+                        geo = (geo & ~(0xffu << (16 + 8 * hf))) | (((Lh(hf) - 2 * ED) & 0xffu) << (16 + 8 * hf));
+                        const int pad = (int)(GS * R) - (int)Lh(hf);
                         int nn = 0;
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -1421,14 +1425,13 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                         }
                         again = again || chain[hf] || !drained;
                     } else {
-                        wstart[hf] = cx[hf];
                         Wn[hf] = cy[hf] - cx[hf];
                         st[hf] = HF_SWEEP;
                         const uint32_t lim = min(Wn[hf], kRingP);
                         if (gl * 16 < lim) *reinterpret_cast<uint4*>(rings + hf * kRingP + gl * 16) = txt[hf];
                         for (uint32_t base = 16 * GS; base < lim; base += 16 * GS) {  // windows beyond 256 symbols
                             const uint32_t col = base + gl * 16;
-                            if (col < lim) *reinterpret_cast<uint4*>(rings + hf * kRingP + col) = load16(ix.text, ix.n, wstart[hf] + col);
+                            if (col < lim) *reinterpret_cast<uint4*>(rings + hf * kRingP + col) = load16(ix.text, ix.n, cx[hf] + col);
                         }
                     }
                 }
@@ -1453,12 +1456,11 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
 #pragma unroll
                     for (int hf = 0; hf < 2; hf++) {
                         if (st[hf] != HF_SWEEP) continue;
-                        const uint32_t slack = Wn[hf] > L[hf] ? (Wn[hf] - L[hf]) / 2 : 0;
-                        tj = max(tj, (Wn[hf] > thr[hf] ? Wn[hf] - thr[hf] : 0) + GS + 12);
-                        tt = max(tt, slack + thr[hf] + thr[hf] / R + 10);
+                        const uint32_t slack = Wn[hf] > Lh(hf) ? (Wn[hf] - Lh(hf)) / 2 : 0;
+                        tj = max(tj, (Wn[hf] > thrh(hf) ? Wn[hf] - thrh(hf) : 0) + GS + 12);
+                        tt = max(tt, slack + thrh(hf) + thrh(hf) / R + 10);
                     }
-                    next_check = max(32u, (tj + 3) & ~3u);
-                    second_check = (tt + 3) & ~3u;
+                    checks = min(max(32u, (tj + 3) & ~3u), 0xfffcu) | (min((tt + 3) & ~3u, 0xfffcu) << 16);
                 }
                 phase = PH_SWEEP;
             } else {
@@ -1474,15 +1476,16 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
             for (int hf = 0; hf < 2; hf++) {
                 if (Wn[hf] > kRingP && t >= kRingP / 2 + GS && ((t - GS) & (kRingP / 2 - 1)) == 0) {
                     const uint32_t from = (t - GS) + kRingP / 2, to = min(Wn[hf], from + kRingP / 2);
+                    const uint32_t wstart = a.cand[g[hf]].x;  // long windows only: not worth a register
                     for (uint32_t col = from + gl; col < to; col += GS) {
-                        uint32_t pos = wstart[hf] + col;
+                        uint32_t pos = wstart + col;
                         rings[hf * kRingP + (col & (kRingP - 1))] = pos < ix.n ? ix.text[pos] : (uint8_t)7;
                     }
                 }
             }
             // Decision point (bounds as in k_evaluate): a half passes as soon as its
             // maximum reaches the threshold and fails as soon as no alignment through unswept cells can.
-            if (__builtin_expect(t >= next_check, 0)) {
+            if (__builtin_expect(t >= (checks & 0xffffu), 0)) {
                 int bmax[2], ub[2];
                 // one bound per lane instead of one per row: the lane's largest H with the row count of
                 // its first real row (at most R - 1 looser than the per-row bound of k_evaluate)
@@ -1491,7 +1494,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                 for (int r = 1; r < R; r++) hm = pku_max(hm, h[r]);
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    const int W_ = (int)Wn[hf], L_ = (int)L[hf];
+                    const int W_ = (int)Wn[hf], L_ = (int)Lh(hf);
                     const int jl = (int)t - 1 - (int)gl;
                     const int jc = min(jl, W_ - 1);
                     const int cols_left = W_ - 1 - jc;
@@ -1510,13 +1513,12 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
                 for (int hf = 0; hf < 2; hf++) {
                     if (st[hf] == HF_SWEEP) {
                         const int u = max(max(ub[hf], bmax[hf]), (int)Wn[hf] - (int)t + GS);  // or starts in unswept columns
-                        if (bmax[hf] >= (int)thr[hf]) st[hf] = HF_PASS;
-                        else if (u < (int)thr[hf] || t >= Wn[hf] + GS - 1) st[hf] = HF_FAIL;
+                        if (bmax[hf] >= (int)thrh(hf)) st[hf] = HF_PASS;
+                        else if (u < (int)thrh(hf) || t >= Wn[hf] + GS - 1) st[hf] = HF_FAIL;
                     }
                 }
                 finish = st[0] != HF_SWEEP && st[1] != HF_SWEEP;
-                next_check = second_check > t + 8 ? second_check : t + kDecide;
-                second_check = 0;
+                checks = (checks >> 16) > t + 8 ? (checks >> 16) : min(t + kDecide, 0xfffcu);  // past 65 k columns: every trip
             }
             if (!finish) {
                 // four columns per trip: this lane's columns j0 .. j0+3 of both windows come from the rings as two
@@ -1575,7 +1577,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
             bm[1] = row_max16(bm[1]);
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
-                if (st[hf] == HF_SWEEP) st[hf] = bm[hf] >= (int)thr[hf] ? HF_PASS : HF_FAIL;
+                if (st[hf] == HF_SWEEP) st[hf] = bm[hf] >= (int)thrh(hf) ? HF_PASS : HF_FAIL;
                 if (st[hf] == HF_PASS) {
                     if (gl == 0) passed[hf] = g[hf];
                 } else if (st[hf] == HF_FAIL) {
@@ -1614,17 +1616,14 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView i
         base = __builtin_amdgcn_readfirstlane(base);
         if (lane < pend) a.pass_list[base + lane] = pend_buf[lane];
     }
-    if (gl != 0) {
-        verified = 0;
-        wbytes = 0;
-    }
+    unsigned long long v64 = gl == 0 ? verified : 0, w64 = gl == 0 ? wbytes : 0;
     for (int d = 32; d > 0; d >>= 1) {
-        verified += __shfl_down(verified, d);
-        wbytes += __shfl_down(wbytes, d);
+        v64 += __shfl_down(v64, d);
+        w64 += __shfl_down(w64, d);
     }
-    if (lane == 0 && verified) {
-        atomicAdd(a.n_verified, verified);
-        atomicAdd(a.window_bytes, wbytes);
+    if (lane == 0 && v64) {
+        atomicAdd(a.n_verified, v64);
+        atomicAdd(a.window_bytes, w64);
     }
 }
 
