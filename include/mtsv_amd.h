@@ -94,7 +94,8 @@ typedef struct {
     uint64_t window_bytes;  /* summed window length of those */
     uint64_t n_hits;        /* hits returned */
     uint64_t n_passes;      /* >1 when the batch had to be split to fit the hit workspace */
-    uint64_t n_rounds;      /* verification rounds of the last pass (same-TaxId chains) */
+    uint64_t n_rounds;      /* verification rounds of the last pass: 1 + rounds that took the successors of
+                             * candidates that passed the SW prefilter and failed the edit distance */
 } mtsv_batch_stats;
 
 const char *mtsv_last_error(void);
