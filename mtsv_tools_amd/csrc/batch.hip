@@ -47,19 +47,30 @@ void dev_alloc(T** p, uint64_t count, uint64_t* bytes) {
 }
 }  // namespace
 
-Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t max_bases_, uint64_t hit_cap_)
-    : ix(ix_), di(di_), max_reads(max_reads_), max_bases(max_bases_), hit_cap(hit_cap_) {
+constexpr uint64_t kLaneMinReads = 32768;  // a lane below this many reads does not fill the device
+
+Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t max_bases_, uint64_t hit_cap_, Batch* parent_)
+    : ix(ix_), di(di_), max_reads(max_reads_), max_bases(max_bases_), hit_cap(hit_cap_), parent(parent_) {
     if (max_reads == 0) max_reads = 1;
     if (max_reads > 0x7fffffffull) throw std::runtime_error("limit: more than 2^31 reads in one batch");
     if (max_bases >= 0xffffffffull) throw std::runtime_error("limit: 4 GiB of bases or more in one batch");
-    if (hit_cap == 0) hit_cap = std::max<uint64_t>(1ull << 20, 32 * max_reads);
+    const uint64_t hit_cap_user = hit_cap;
+    if (!parent) {
+        n_lanes = 3;
+        if (const char* e = getenv("MTSV_LANES")) n_lanes = std::max(1, std::min(8, atoi(e)));
+        if (max_reads < (uint64_t)n_lanes * kLaneMinReads) n_lanes = 1;
+    }
+    ws_reads = (max_reads + n_lanes - 1) / n_lanes;
+    if (hit_cap == 0) hit_cap = std::max<uint64_t>(1ull << 20, 32 * ws_reads);
     if (hit_cap > 0xfffffff0ull) hit_cap = 0xfffffff0ull;
-    hits_cap = std::max<uint64_t>(1ull << 20, 16 * max_reads);
+    hits_cap = std::max<uint64_t>(1ull << 20, 16 * ws_reads);
     HIP_CHECK(hipSetDevice(di->device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
-    const uint64_t ns = 2 * max_reads;
-    dev_alloc(&d_bases, max_bases + 64, &bytes);  // k_search reads up to 36 bytes past a seed start with dword loads
-    dev_alloc(&d_read_off, max_reads + 1, &bytes);
+    const uint64_t ns = 2 * ws_reads;
+    if (!parent) {
+        dev_alloc(&d_bases, max_bases + 64, &bytes);  // k_search reads up to 36 bytes past a seed start with dword loads
+        dev_alloc(&d_read_off, max_reads + 1, &bytes);
+    }
     dev_alloc(&d_strand_hits, ns + 1, &bytes);
     dev_alloc(&d_strand_nseeds, ns, &bytes);
     dev_alloc(&d_strand_off, ns + 1, &bytes);
@@ -85,9 +96,14 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
+    for (int k = 1; k < n_lanes; k++) {
+        extra.emplace_back(new Batch(ix, di, ws_reads, 0, hit_cap_user, this));
+        bytes += extra.back()->bytes;
+    }
 }
 
 Batch::~Batch() {
+    extra.clear();
     (void)hipSetDevice(di->device);
     (void)hipStreamSynchronize(stream);
     for (void* p : {(void*)d_bases, (void*)d_read_off, (void*)d_seed_lo, (void*)d_seed_cnt, (void*)d_seed_pre, (void*)d_strand_hits,
@@ -127,14 +143,13 @@ void Batch::upload(const uint8_t* bases, const uint64_t* read_off, uint64_t n) {
     HIP_CHECK(hipStreamSynchronize(stream));
     n_reads = n;
     n_hits_total = 0;
+    total_hits = 0;
+    segments.clear();
 }
 
 // counters in d_counters: [0] scan total (u64), [1] wl_count (u32), [2] lf_steps, [3] n_cand,
 // [4] n_verified, [5] window_bytes, [6] second scan total
-void Batch::begin_run(const mtsv_params& p) {
-    if (!(p.edit_rate >= 0.0 && p.edit_rate <= 1.0)) throw std::runtime_error("arg: edit_rate must be within [0, 1]");
-    if (!(p.min_seed >= 0.0) || !std::isfinite(p.min_seed)) throw std::runtime_error("arg: min_seed must be finite and >= 0");
-    if (p.seed_size == 0 || p.seed_interval == 0) throw std::runtime_error("arg: seed_size and seed_interval must be > 0");
+void Batch::reset_lane() {
     HIP_CHECK(hipSetDevice(di->device));
     memset(&stats, 0, sizeof stats);
     memset(stage_acc, 0, sizeof stage_acc);
@@ -143,24 +158,106 @@ void Batch::begin_run(const mtsv_params& p) {
     HIP_CHECK(hipEventRecord(ev[8], stream));
 }
 
-void Batch::end_run() {
+void Batch::finish_lane() {
     HIP_CHECK(hipEventRecord(ev[9], stream));
     HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipEventElapsedTime(&stage_acc[7], ev[8], ev[9]));
-    for (int s = 0; s < MTSV_N_STAGES; s++) stats.stage_ms[s] = stage_acc[s];
-    stats.n_reads = n_reads;
     stats.lf_steps = h_counters[2];
     stats.n_candidates = h_counters[3];
     stats.n_verified = h_counters[4];
     stats.window_bytes = h_counters[5];
-    stats.n_hits = n_hits_total;
+}
+
+void Batch::begin_run(const mtsv_params& p) {
+    if (!(p.edit_rate >= 0.0 && p.edit_rate <= 1.0)) throw std::runtime_error("arg: edit_rate must be within [0, 1]");
+    if (!(p.min_seed >= 0.0) || !std::isfinite(p.min_seed)) throw std::runtime_error("arg: min_seed must be finite and >= 0");
+    if (p.seed_size == 0 || p.seed_interval == 0) throw std::runtime_error("arg: seed_size and seed_interval must be > 0");
+    segments.clear();
+    total_hits = 0;
+    run_t0 = now_s();
+    reset_lane();
+    for (auto& l : extra) {
+        l->verify_mode = verify_mode;
+        l->sw_pairs = sw_pairs;
+        l->reset_lane();
+    }
+}
+
+void Batch::end_run() {
+    finish_lane();
+    for (auto& l : extra) l->finish_lane();
+    const double wall_ms = (now_s() - run_t0) * 1e3;
+    // stage times are summed over the lanes (device time per stage); the total is the wall time of the
+    // run when lanes overlapped, the stream's own event span otherwise
+    bool overlapped = false;
+    for (auto& l : extra) {
+        if (l->stats.n_passes == 0) continue;
+        overlapped = true;
+        for (int s = 0; s < 7; s++) stage_acc[s] += l->stage_acc[s];
+        stats.n_seed_slots += l->stats.n_seed_slots;
+        stats.n_seed_hits += l->stats.n_seed_hits;
+        stats.n_passes += l->stats.n_passes;
+        stats.n_rounds = std::max(stats.n_rounds, l->stats.n_rounds);
+        stats.lf_steps += l->stats.lf_steps;
+        stats.n_candidates += l->stats.n_candidates;
+        stats.n_verified += l->stats.n_verified;
+        stats.window_bytes += l->stats.window_bytes;
+    }
+    if (overlapped) stage_acc[7] = (float)wall_ms;
+    for (int s = 0; s < MTSV_N_STAGES; s++) stats.stage_ms[s] = stage_acc[s];
+    stats.n_reads = n_reads;
+    total_hits = 0;
+    for (auto& sg : segments) total_hits += sg.count;
+    stats.n_hits = total_hits;
 }
 
 void Batch::run(const mtsv_params& p) {
     begin_run(p);
-    run_slice(p, d_bases, d_read_off, n_reads, max_len, 0);
+    run_range(p, d_bases, d_read_off, n_reads, max_len, 0);
     end_run();
+}
+
+// A resident range of reads, split over the lanes; the hits stay in the lanes, `segments` records them in
+// read order.
+void Batch::run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n, uint32_t range_max_len,
+                      uint64_t read_base) {
+    std::vector<Batch*> ls{this};
+    for (auto& l : extra) ls.push_back(l.get());
+    uint64_t k = n >= ls.size() * kLaneMinReads ? ls.size() : std::max<uint64_t>(1, (n + ws_reads - 1) / ws_reads);
+    k = std::min<uint64_t>(k, ls.size());
+    const uint64_t per = (n + k - 1) / k;
+    if (per > ws_reads) throw std::runtime_error("arg: range holds more reads than the workspace was created for");
+    std::vector<uint64_t> before(k);
+    for (uint64_t i = 0; i < k; i++) before[i] = ls[i]->n_hits_total;
+    auto part = [&](uint64_t i) {
+        const uint64_t a = std::min(n, i * per), b = std::min(n, (i + 1) * per);
+        ls[i]->run_slice(p, sb, so + a, b - a, range_max_len, read_base + a);
+    };
+    if (k == 1) {
+        part(0);
+    } else {
+        std::vector<std::exception_ptr> errs(k);
+        std::vector<std::thread> th;
+        for (uint64_t i = 1; i < k; i++)
+            th.emplace_back([&, i] {
+                try {
+                    HIP_CHECK(hipSetDevice(di->device));
+                    part(i);
+                } catch (...) {
+                    errs[i] = std::current_exception();
+                }
+            });
+        try {
+            part(0);
+        } catch (...) {
+            errs[0] = std::current_exception();
+        }
+        for (auto& t : th) t.join();
+        for (auto& e : errs)
+            if (e) std::rethrow_exception(e);
+    }
+    for (uint64_t i = 0; i < k; i++) segments.push_back(Segment{ls[i], before[i], ls[i]->n_hits_total - before[i]});
 }
 
 // One slice of reads already in HBM (bases `sb`, offsets `so`, `n_slice` reads whose first read is
@@ -439,7 +536,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
             }
             max_len = std::max(max_len, sl.max_len);
             const double t0 = now_s();
-            run_slice(p, buf_b[k & 1], buf_o[k & 1], sl.end - sl.begin, sl.max_len, sl.begin);
+            run_range(p, buf_b[k & 1], buf_o[k & 1], sl.end - sl.begin, sl.max_len, sl.begin);
             if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -462,23 +559,28 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
 
 void Batch::download(mtsv_hit** hits, uint64_t* n) {
     HIP_CHECK(hipSetDevice(di->device));
-    mtsv_hit* h = (mtsv_hit*)malloc(std::max<uint64_t>(n_hits_total, 1) * sizeof(mtsv_hit));
+    mtsv_hit* h = (mtsv_hit*)malloc(std::max<uint64_t>(total_hits, 1) * sizeof(mtsv_hit));
     if (!h) throw std::runtime_error("nomem: result array");
-    if (n_hits_total) {
+    if (total_hits) {
         // fault the fresh pages in from several threads: a D2H copy into untouched malloc memory is
         // page-fault bound (~12 GB/s instead of ~55)
         uint8_t* hb = (uint8_t*)h;
-        parallel_ranges(n_hits_total * sizeof(mtsv_hit), [=](uint64_t a, uint64_t b) {
+        parallel_ranges(total_hits * sizeof(mtsv_hit), [=](uint64_t a, uint64_t b) {
             for (uint64_t o = a; o < b; o += 4096) hb[o] = 0;
         });
-        hipError_t e = hipMemcpy(h, d_hits, n_hits_total * sizeof(mtsv_hit), hipMemcpyDeviceToHost);
-        if (e != hipSuccess) {
-            free(h);
-            throw_hip(e, "hipMemcpy(hits)", __FILE__, __LINE__);
+        uint64_t at = 0;
+        for (auto& sg : segments) {
+            if (!sg.count) continue;
+            hipError_t e = hipMemcpy(h + at, sg.lane->d_hits + sg.offset, sg.count * sizeof(mtsv_hit), hipMemcpyDeviceToHost);
+            if (e != hipSuccess) {
+                free(h);
+                throw_hip(e, "hipMemcpy(hits)", __FILE__, __LINE__);
+            }
+            at += sg.count;
         }
     }
     *hits = h;
-    *n = n_hits_total;
+    *n = total_hits;
 }
 
 }  // namespace mtsv

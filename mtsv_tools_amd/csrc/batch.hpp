@@ -1,5 +1,6 @@
 // batch.hpp -- device workspace of one read batch (see batch.hip).
 #pragma once
+#include <memory>
 #include <vector>
 
 #include "../../include/mtsv_amd.h"
@@ -14,6 +15,21 @@ struct Batch {
     hipStream_t stream = nullptr, copy_stream = nullptr;
     uint64_t max_reads, max_bases, hit_cap, hits_cap = 0;
     uint64_t bytes = 0;
+    // Lanes: the workspace is cut into n_lanes equal parts, each with its own stream; a resident range of
+    // reads is split across them and the parts run concurrently (one host thread each), so that the
+    // HBM-latency-bound stages of one part overlap the VALU-bound verification of another.  The owner
+    // is lane 0 and holds the input buffers; the other lanes borrow them.  MTSV_LANES=1 disables it.
+    Batch* parent = nullptr;
+    std::vector<std::unique_ptr<Batch>> extra;
+    int n_lanes = 1;
+    uint64_t ws_reads = 0;  // reads one lane's workspace is sized for
+    struct Segment {
+        Batch* lane;
+        uint64_t offset, count;
+    };
+    std::vector<Segment> segments;  // where the hits of the last run sit, in read order
+    uint64_t total_hits = 0;
+    double run_t0 = 0;
 
     uint8_t *d_bases = nullptr, *d_bases2 = nullptr;  // second input buffer: run_host() double-buffers slices
     uint32_t *d_read_off = nullptr, *d_read_off2 = nullptr;
@@ -43,7 +59,7 @@ struct Batch {
     mtsv_batch_stats stats{};
     float stage_acc[MTSV_N_STAGES] = {0};
 
-    Batch(mtsv_index* ix, DeviceIndex* di, uint64_t max_reads, uint64_t max_bases, uint64_t hit_cap);
+    Batch(mtsv_index* ix, DeviceIndex* di, uint64_t max_reads, uint64_t max_bases, uint64_t hit_cap, Batch* parent = nullptr);
     ~Batch();
     Batch(const Batch&) = delete;
     Batch& operator=(const Batch&) = delete;
@@ -55,6 +71,10 @@ struct Batch {
 
    private:
     void begin_run(const mtsv_params& p);
+    void reset_lane();
+    void finish_lane();
+    void run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n, uint32_t range_max_len,
+                   uint64_t read_base);
     void run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n_slice, uint32_t slice_max_len,
                    uint64_t read_base);
     void end_run();

@@ -1265,11 +1265,15 @@ __device__ inline int row_max16(int v) {
     return v;
 }
 
+#ifndef MTSV_SW_OCC
+#define MTSV_SW_OCC 4
+#endif
+constexpr int kSwOcc = MTSV_SW_OCC;  // resident workgroups of k_sw_pairs per CU
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
 constexpr uint32_t kDecide = 32;  // columns between decision points after the two scheduled ones
 
 template <int R>
-__global__ __launch_bounds__(256, R > 10 ? 2 : 5) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
+__global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     constexpr int GS = 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
     __shared__ uint32_t pend_all[256 / kWave][kWave + 8];  // passed candidates, flushed with one atomic per ~64
@@ -2012,7 +2016,7 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
 void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
     // persistent 16-lane groups, two candidates per group: one resident generation of blocks pulls the worklist
 #define SW_CASE(RR)                                                                                                      \
-    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 2 : 5)))), \
+    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 2 : kSwOcc)))), \
                        dim3(256), 0, s, ix, a)
     if (max_len <= 64) SW_CASE(4);
     else if (max_len <= 96) SW_CASE(6);
