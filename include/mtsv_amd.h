@@ -96,6 +96,9 @@ typedef struct {
     uint64_t n_passes;      /* >1 when the batch had to be split to fit the hit workspace */
     uint64_t n_rounds;      /* verification rounds of the last pass: 1 + rounds that took the successors of
                              * candidates that passed the SW prefilter and failed the edit distance */
+    uint64_t n_lanes;       /* concurrent parts the batch ran as (MTSV_LANES, default 3 for >= 98304 reads): with
+                             * more than one, stage_ms[0..6] are device times summed over the overlapping parts
+                             * and stage_ms[7] is the wall time of the run */
 } mtsv_batch_stats;
 
 const char *mtsv_last_error(void);

@@ -40,7 +40,7 @@ class BatchStats(C.Structure):  # mtsv_batch_stats
                 ("n_seed_slots", C.c_uint64), ("n_seed_hits", C.c_uint64), ("lf_steps", C.c_uint64),
                 ("n_candidates", C.c_uint64), ("n_verified", C.c_uint64),
                 ("window_bytes", C.c_uint64), ("n_hits", C.c_uint64), ("n_passes", C.c_uint64),
-                ("n_rounds", C.c_uint64)]
+                ("n_rounds", C.c_uint64), ("n_lanes", C.c_uint64)]
 
     def as_dict(self):
         d = {n: int(getattr(self, n)) for n, _ in self._fields_[1:]}

@@ -175,6 +175,7 @@ void Batch::begin_run(const mtsv_params& p) {
     if (p.seed_size == 0 || p.seed_interval == 0) throw std::runtime_error("arg: seed_size and seed_interval must be > 0");
     segments.clear();
     total_hits = 0;
+    lanes_used = 1;
     run_t0 = now_s();
     reset_lane();
     for (auto& l : extra) {
@@ -207,6 +208,7 @@ void Batch::end_run() {
     if (overlapped) stage_acc[7] = (float)wall_ms;
     for (int s = 0; s < MTSV_N_STAGES; s++) stats.stage_ms[s] = stage_acc[s];
     stats.n_reads = n_reads;
+    stats.n_lanes = lanes_used;
     total_hits = 0;
     for (auto& sg : segments) total_hits += sg.count;
     stats.n_hits = total_hits;
@@ -228,6 +230,7 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
     k = std::min<uint64_t>(k, ls.size());
     const uint64_t per = (n + k - 1) / k;
     if (per > ws_reads) throw std::runtime_error("arg: range holds more reads than the workspace was created for");
+    lanes_used = std::max<uint64_t>(lanes_used, k);
     std::vector<uint64_t> before(k);
     for (uint64_t i = 0; i < k; i++) before[i] = ls[i]->n_hits_total;
     auto part = [&](uint64_t i) {

@@ -30,6 +30,7 @@ struct Batch {
     std::vector<Segment> segments;  // where the hits of the last run sit, in read order
     uint64_t total_hits = 0;
     double run_t0 = 0;
+    uint64_t lanes_used = 1;
 
     uint8_t *d_bases = nullptr, *d_bases2 = nullptr;  // second input buffer: run_host() double-buffers slices
     uint32_t *d_read_off = nullptr, *d_read_off2 = nullptr;
