@@ -2,6 +2,7 @@
 // path.  Replaces the producer -> workers -> joiner queue of vendor/cue/src/lib.rs:45-105 with
 // large HBM-resident batches: reads stay on the device between stages, every stage is one launch
 // over the whole batch, and the only host round-trips are two 8-byte totals per pass.
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -48,6 +49,7 @@ void dev_alloc(T** p, uint64_t count, uint64_t* bytes) {
 }  // namespace
 
 constexpr uint64_t kLaneMinReads = 32768;  // a lane below this many reads does not fill the device
+constexpr uint64_t kChunkMaxReads = 4ull << 20;  // lanes take a range in chunks of at most this many reads (smaller chunks measured slower: per-pass launches and host round trips)
 
 Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t max_bases_, uint64_t hit_cap_, Batch* parent_)
     : ix(ix_), di(di_), max_reads(max_reads_), max_bases(max_bases_), hit_cap(hit_cap_), parent(parent_) {
@@ -61,6 +63,11 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
         if (max_reads < (uint64_t)n_lanes * kLaneMinReads) n_lanes = 1;
     }
     ws_reads = (max_reads + n_lanes - 1) / n_lanes;
+    if (!parent && n_lanes > 1) {
+        uint64_t cmax = kChunkMaxReads;
+        if (const char* e = getenv("MTSV_CHUNK")) cmax = std::max<uint64_t>(kLaneMinReads, strtoull(e, nullptr, 10));
+        ws_reads = std::min(ws_reads, cmax);
+    }
     if (hit_cap == 0) hit_cap = std::max<uint64_t>(1ull << 20, 32 * ws_reads);
     if (hit_cap > 0xfffffff0ull) hit_cap = 0xfffffff0ull;
     hits_cap = std::max<uint64_t>(1ull << 20, 16 * ws_reads);
@@ -226,19 +233,28 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                       uint64_t read_base) {
     std::vector<Batch*> ls{this};
     for (auto& l : extra) ls.push_back(l.get());
-    uint64_t k = n >= ls.size() * kLaneMinReads ? ls.size() : std::max<uint64_t>(1, (n + ws_reads - 1) / ws_reads);
-    k = std::min<uint64_t>(k, ls.size());
-    const uint64_t per = (n + k - 1) / k;
+    // Chunks of at most ws_reads reads, handed to the lanes from a shared counter: after the first chunk the
+    // lanes drift apart, so one lane's index lookups run under another lane's prefilter.
+    uint64_t k = n >= ls.size() * kLaneMinReads ? ls.size() : 1;
+    const uint64_t n_chunks = std::max<uint64_t>(k, (n + ws_reads - 1) / ws_reads);
+    const uint64_t per = (n + n_chunks - 1) / n_chunks;
     if (per > ws_reads) throw std::runtime_error("arg: range holds more reads than the workspace was created for");
+    k = std::min(k, n_chunks);
     lanes_used = std::max<uint64_t>(lanes_used, k);
-    std::vector<uint64_t> before(k);
-    for (uint64_t i = 0; i < k; i++) before[i] = ls[i]->n_hits_total;
-    auto part = [&](uint64_t i) {
-        const uint64_t a = std::min(n, i * per), b = std::min(n, (i + 1) * per);
-        ls[i]->run_slice(p, sb, so + a, b - a, range_max_len, read_base + a);
+    std::vector<Segment> segs(n_chunks);
+    std::atomic<uint64_t> next{0};
+    auto work = [&](Batch* lane) {
+        for (;;) {
+            const uint64_t c = next.fetch_add(1);
+            if (c >= n_chunks) return;
+            const uint64_t a = std::min(n, c * per), b = std::min(n, (c + 1) * per);
+            const uint64_t before = lane->n_hits_total;
+            lane->run_slice(p, sb, so + a, b - a, range_max_len, read_base + a);
+            segs[c] = Segment{lane, before, lane->n_hits_total - before};
+        }
     };
     if (k == 1) {
-        part(0);
+        work(this);
     } else {
         std::vector<std::exception_ptr> errs(k);
         std::vector<std::thread> th;
@@ -246,21 +262,23 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             th.emplace_back([&, i] {
                 try {
                     HIP_CHECK(hipSetDevice(di->device));
-                    part(i);
+                    work(ls[i]);
                 } catch (...) {
                     errs[i] = std::current_exception();
+                    next.store(n_chunks);  // stop the others
                 }
             });
         try {
-            part(0);
+            work(this);
         } catch (...) {
             errs[0] = std::current_exception();
+            next.store(n_chunks);
         }
         for (auto& t : th) t.join();
         for (auto& e : errs)
             if (e) std::rethrow_exception(e);
     }
-    for (uint64_t i = 0; i < k; i++) segments.push_back(Segment{ls[i], before[i], ls[i]->n_hits_total - before[i]});
+    for (auto& sg : segs) segments.push_back(sg);
 }
 
 // One slice of reads already in HBM (bases `sb`, offsets `so`, `n_slice` reads whose first read is
