@@ -60,7 +60,7 @@ def pmc(dfetch, dwrite, workload, out, traffic):
     fetch, write = pipeline("FETCH_SIZE_KB"), pipeline("WRITE_SIZE_KB")
     summary = {
         "workload": workload, "dev_flags": 0,
-        "source": f"{os.path.join('profiles', os.path.basename(out))} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `bench.py --no-extras`; per-step = per-kernel sums / pipeline passes in the profiled process)",
+        "source": f"{os.path.join('profiles', 'r01_' + workload + '_hbm_pmc.json')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `MTSV_LANES=1 bench.py --no-extras`; per-step = per-kernel sums / pipeline passes in the profiled process)",
         "fetch_bytes_per_step_raw": fetch, "write_bytes_per_step": write, "hbm_bytes_per_step": fetch + write,
         "note": "FETCH_SIZE is in KiB and, per MI355X_MICROARCH.md, under-reports wide coalesced streams by 2x on gfx950; this path's 16-B-per-lane random gathers are uncalibrated, so the raw counter is quoted (with the 2x correction: fetch*2+write)",
         "hbm_bytes_per_step_with_2x_fetch_correction": 2 * fetch + write,
