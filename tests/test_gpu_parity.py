@@ -341,6 +341,35 @@ def medium():
     return ix, bases, off
 
 
+def test_lanes_do_not_change_hits_or_counters(medium, monkeypatch):
+    """A resident batch above 98 304 reads runs as three concurrent lanes (own streams, host threads);
+    one lane, two and three must give the same hits in the same order and the same work counters, for
+    both evaluation orders and for the sliced host path."""
+    ix, bases, off = medium
+    ix.to_device(0)
+    n = len(off) - 1
+    ref = None
+    for lanes in ("1", "2", "3"):
+        monkeypatch.setenv("MTSV_LANES", lanes)
+        b = M.Batch(ix, 0, n, len(bases))
+        b.upload(bases, off)
+        for mode in (0, 1):
+            b.set_verify_mode(mode)
+            b.run()
+            st = b.stats()
+            assert st["n_lanes"] == int(lanes)
+            got = (b.download(), {k: st[k] for k in ("n_seed_hits", "n_candidates", "n_verified", "window_bytes", "n_hits")})
+            if ref is None:
+                ref = got
+            assert_same_hits(got[0], ref[0])
+            assert got[1] == ref[1]
+        b.close()
+        b = M.Batch(ix, 0, 120000, 120000 * 150)      # host path: slices of 120 k reads, each split over the lanes
+        b.run_host(bases, off)
+        assert_same_hits(b.download(), ref[0])
+        b.close()
+
+
 def test_full_size_properties(medium, tmp_path):
     """size-independent properties at a batch the oracle cannot finish in seconds:
     idempotence, shard invariance (two halves == whole: the multi-GPU read sharding), strand
