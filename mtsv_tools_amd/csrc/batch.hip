@@ -101,6 +101,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_hits, hits_cap, &bytes);
     HIP_CHECK(hipHostMalloc((void**)&h_counters, kCounters * sizeof(uint64_t)));
     if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
+    if (const char* e = getenv("MTSV_SW_DIAG")) sw_diag = atoi(e) != 0;
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
     for (int k = 1; k < n_lanes; k++) {
@@ -188,6 +189,7 @@ void Batch::begin_run(const mtsv_params& p) {
     for (auto& l : extra) {
         l->verify_mode = verify_mode;
         l->sw_pairs = sw_pairs;
+        l->sw_diag = sw_diag;
         l->reset_lane();
     }
 }
@@ -392,6 +394,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     HIP_CHECK(hipMemsetAsync(d_counters + 8, 0, 3 * sizeof(uint64_t), stream));
                     HIP_CHECK(hipMemsetAsync(next_slot, 0, sizeof(uint64_t), stream));
                     EvalArgs sw = a;
+                    sw.flags = sw_diag ? 0u : 1u;
                     sw.worklist = wl;
                     sw.wl_count = wl_count;
                     sw.wl_cursor = (uint32_t*)(d_counters + 8);

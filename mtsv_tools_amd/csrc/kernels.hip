@@ -1272,16 +1272,30 @@ constexpr int kSwOcc = MTSV_SW_OCC;  // resident workgroups of k_sw_pairs per CU
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
 constexpr uint32_t kDecide = 32;  // columns between decision points after the two scheduled ones
 
+constexpr uint32_t kPend = 32;  // passed candidates a group of k_sw_pairs buffers before one atomic
+
 template <int R>
-__global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
+__global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     constexpr int GS = 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
-    __shared__ uint32_t pend_all[256 / kWave][kWave + 8];  // passed candidates, flushed with one atomic per ~64
+    __shared__ uint32_t pend_all[256 / GS][kPend];  // a group's passed candidates, flushed with one atomic per kPend
     __shared__ uint32_t meta_all[256 / GS][4][8];         // the group's claimed work items, staged by lanes 0..3
     const uint32_t lane = lane_id();
     const uint32_t gl = lane & (GS - 1);
-    uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
-    uint32_t pend = 0;  // wave-uniform
+    uint32_t* pend_buf = pend_all[threadIdx.x / GS];
+    uint32_t pend = 0;  // group-uniform
+    // append candidate gq to the pass list (all lanes of the group call it together)
+    auto pass_push = [&](uint32_t gq) {
+        if (gl == 0) pend_buf[pend] = gq;
+        pend++;
+        if (pend == kPend) {
+            uint32_t base = 0;
+            if (gl == 0) base = atomicAdd(a.pass_count, kPend);
+            base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
+            for (uint32_t i = gl; i < kPend; i += GS) a.pass_list[base + i] = pend_buf[i];
+            pend = 0;
+        }
+    };
     const uint32_t n_work = *a.wl_count;
     const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
                                                : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
@@ -1289,14 +1303,16 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
 
     uint32_t phase = PH_FETCH;
     uint32_t loc = 0, loc_end = 0;  // position inside the claimed slice of <= 4 items
-    bool drained = false;
     // per-half state; index 0 = low half
     uint32_t st[2] = {HF_EMPTY, HF_EMPTY};
     uint32_t g[2] = {0, 0}, o[2] = {0, 0}, Wn[2] = {0, 0};
     uint32_t geo = 0;  // read length (<= 253) and SW threshold of both halves, one byte each: L0 L1 thr0 thr1
     auto Lh = [&](int hf) { return (geo >> (8 * hf)) & 0xffu; };
     auto thrh = [&](int hf) { return (geo >> (16 + 8 * hf)) & 0xffu; };
-    bool chain[2] = {false, false}, hopeless[2] = {false, false};
+    // group-uniform flags kept as bits of one VGPR (as separate bools they live in SGPR pairs, and this
+    // kernel is already at the SGPR limit): bit hf = chain pending, 2 + hf = hopeless read, 4 = worklist drained
+    uint32_t gf = 0;
+    constexpr uint32_t F_CHAIN = 1u, F_HOPELESS = 4u, F_DRAINED = 16u;
     uint32_t qc2[R];  // read codes << 1, both halves
     uint32_t h[R], up_prev = 0, best = 0;
     uint32_t t = 0, steps = 0;
@@ -1316,7 +1332,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
             // candidates and issues the loads (window text, read bytes), pass 2 consumes them.  Repeats
             // only when a freshly loaded read turns out to hold more N than the edit tolerance.
             for (;;) {
-                bool want[2] = {false, false}, fresh[2] = {false, false};
+                uint32_t wf = 0;  // bit hf = this half takes a candidate in this pass, 2 + hf = with a new read
                 uint32_t cx[2] = {0, 0}, cy[2] = {0, 0}, b0s[2] = {0, 0}, strands[2] = {0, 0};
                 uint4 txt[2];
                 constexpr int RW = (R + 3) / 4;  // dwords that hold a lane's R read bytes
@@ -1325,13 +1341,13 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
                 for (int hf = 0; hf < 2; hf++) {
                     txt[hf] = make_uint4(0x07070707u, 0x07070707u, 0x07070707u, 0x07070707u);
                     if (st[hf] != HF_EMPTY) continue;
-                    if (chain[hf]) {  // next candidate of the same TaxId: same read rows, new window
+                    if (gf & (F_CHAIN << hf)) {  // next candidate of the same TaxId: same read rows, new window
                         const uint4 c = a.cand[g[hf]];
                         cx[hf] = c.x;
                         cy[hf] = c.y;
-                        chain[hf] = false;
-                        want[hf] = true;
-                    } else if (!drained) {
+                        gf &= ~(F_CHAIN << hf);
+                        wf |= 1u << hf;
+                    } else if (!(gf & F_DRAINED)) {
                         if (loc == loc_end) {
                             uint32_t base = 0;
                             if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
@@ -1357,7 +1373,7 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
                             }
                         }
                         if (loc == loc_end) {
-                            drained = true;
+                            gf |= F_DRAINED;
                         } else {
                             const uint32_t* m = meta + loc * 8;
                             loc++;
@@ -1368,13 +1384,12 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
                             b0s[hf] = m[4];
                             geo = (geo & ~(0xffu << (8 * hf))) | ((m[5] & 0xffu) << (8 * hf));
                             strands[hf] = m[6];
-                            fresh[hf] = true;
-                            want[hf] = true;
+                            wf |= 5u << hf;
                         }
                     }
-                    if (want[hf]) {
+                    if (wf & (1u << hf)) {
                         if (gl * 16 < cy[hf] - cx[hf]) txt[hf] = load16(ix.text, ix.n, cx[hf] + gl * 16);
-                        if (fresh[hf]) {
+                        if (wf & (4u << hf)) {
                             // the lane's rows are R consecutive read bytes (descending for the reverse strand):
                             // aligned dword loads + v_alignbyte; byte k of raw[] is read byte s0 + k
                             const int pad = (int)(GS * R) - (int)Lh(hf);
@@ -1395,8 +1410,8 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
                 bool again = false;
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    if (!want[hf]) continue;
-                    if (fresh[hf]) {
+                    if (!(wf & (1u << hf))) continue;
+                    if (wf & (4u << hf)) {
                         const uint32_t ED = (uint32_t)ceil((double)Lh(hf) * a.edit_rate);  // index.rs:281-282
                         const bool wrapped = 2ull * ED > (uint64_t)Lh(hf);                  // usize wrap of index.rs:406
                         geo = (geo & ~(0xffu << (16 + 8 * hf))) | (((Lh(hf) - 2 * ED) & 0xffu) << (16 + 8 * hf));
@@ -1416,26 +1431,61 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
                         }
                         nn = row_sum16(nn);
                         // more N in the read than the edit tolerance: index.rs:410 fails whatever the prefilter says
-                        hopeless[hf] = wrapped || (uint32_t)nn > ED;
+                        gf = (wrapped || (uint32_t)nn > ED) ? (gf | (F_HOPELESS << hf)) : (gf & ~(F_HOPELESS << hf));
                     }
                     verified++;
                     wbytes += cy[hf] - cx[hf];
-                    if (hopeless[hf]) {  // rejected without a sweep; the reference still ran its prefilter on it
+                    if (gf & (F_HOPELESS << hf)) {  // rejected without a sweep; the reference still ran its prefilter on it
                         if (gl == 0) a.cand_status[g[hf]] = 1;
                         const uint32_t nxt = a.cand_next[g[hf]];
                         if (nxt != 0xffffffffu && nxt < maxc) {
                             g[hf] = o[hf] + nxt;
-                            chain[hf] = true;
+                            gf |= F_CHAIN << hf;
                         }
-                        again = again || chain[hf] || !drained;
+                        again = again || (gf & (F_CHAIN << hf)) || !(gf & F_DRAINED);
                     } else {
                         Wn[hf] = cy[hf] - cx[hf];
-                        st[hf] = HF_SWEEP;
                         const uint32_t lim = min(Wn[hf], kRingP);
                         if (gl * 16 < lim) *reinterpret_cast<uint4*>(rings + hf * kRingP + gl * 16) = txt[hf];
-                        for (uint32_t base = 16 * GS; base < lim; base += 16 * GS) {  // windows beyond 256 symbols
-                            const uint32_t col = base + gl * 16;
+                        static_assert(kRingP == 2 * 16 * GS, "the ring holds two passes of 16 symbols per lane");
+                        {  // windows beyond 256 symbols: the second half of the ring
+                            const uint32_t col = 16 * GS + gl * 16;
                             if (col < lim) *reinterpret_cast<uint4*>(rings + hf * kRingP + col) = load16(ix.text, ix.n, cx[hf] + col);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // other lanes' ring bytes are read next
+                        // A lower bound decides most true candidates without the sweep: the ungapped alignment
+                        // on the diagonal the window was cut around (window start = seed site - (q + ED),
+                        // index.rs:128-133, so read position 0 faces window column ED) scores L - 2*mismatches,
+                        // and the local score is at least that.  mismatches <= ED  =>  score >= L - 2*ED.
+                        const uint32_t Lq = Lh(hf), EDq = (Lq - thrh(hf)) / 2;
+                        bool decided = false;
+                        if (EDq + Lq <= lim && !(a.flags & 1u)) {
+                            const int pad = (int)(GS * R) - (int)Lq;
+                            // the lane's R window symbols on that diagonal: aligned dwords + v_alignbyte
+                            const int base = (int)EDq + (int)(gl * R) - pad;  // negative for padding rows (ignored below)
+                            const uint32_t* ring32 = reinterpret_cast<const uint32_t*>(rings + hf * kRingP);
+                            constexpr int RD = (R + 3) / 4;
+                            uint32_t dd[RD + 1], sy[RD];
+#pragma unroll
+                            for (int k = 0; k <= RD; k++) dd[k] = ring32[(uint32_t)((base >> 2) + k) & (kRingP / 4 - 1)];
+#pragma unroll
+                            for (int k = 0; k < RD; k++) sy[k] = __builtin_amdgcn_alignbyte(dd[k + 1], dd[k], (uint32_t)base & 3u);
+                            int mm = 0;
+#pragma unroll
+                            for (int r = 0; r < R; r++) {
+                                const int p = (int)(gl * R + r) - pad;
+                                const uint32_t sym = (sy[r >> 2] >> (8 * (r & 3))) & 0xffu;
+                                const uint32_t code = (qc2[r] >> (16 * hf + 1)) & 7u;
+                                mm += (p >= 0 && code != sym) ? 1 : 0;
+                            }
+                            mm = row_sum16(mm);
+                            decided = (uint32_t)mm <= EDq && !(a.flags & 4u);
+                        }
+                        if (decided) {
+                            pass_push(g[hf]);  // its edit distance is k_edit_myers' business (index.rs:407-410)
+                            again = again || !(gf & F_DRAINED);
+                        } else {
+                            st[hf] = HF_SWEEP;
                         }
                     }
                 }
@@ -1572,9 +1622,9 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
                 finish = t >= steps;
             }
         }
-        uint32_t passed[2] = {0xffffffffu, 0xffffffffu};
         if (__builtin_expect(phase == PH_SWEEP && finish, 0)) {
             int bm[2];
+
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) bm[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;
             bm[0] = row_max16(bm[0]);
@@ -1583,42 +1633,25 @@ __global__ __launch_bounds__(256, R > 10 ? 2 : kSwOcc) void k_sw_pairs(DevIndexV
             for (int hf = 0; hf < 2; hf++) {
                 if (st[hf] == HF_SWEEP) st[hf] = bm[hf] >= (int)thrh(hf) ? HF_PASS : HF_FAIL;
                 if (st[hf] == HF_PASS) {
-                    if (gl == 0) passed[hf] = g[hf];
+                    pass_push(g[hf]);
                 } else if (st[hf] == HF_FAIL) {
                     if (gl == 0) a.cand_status[g[hf]] = 1;
                     const uint32_t nxt = a.cand_next[g[hf]];  // next candidate of this TaxId in rank order (index.rs:393)
                     if (nxt != 0xffffffffu && nxt < maxc) {
                         g[hf] = o[hf] + nxt;
-                        chain[hf] = true;
+                        gf |= F_CHAIN << hf;
                     }
                 }
                 st[hf] = HF_EMPTY;
             }
             phase = PH_FETCH;
         }
-        // wave-uniform from here: collect the passed candidates of this trip
-#pragma unroll
-        for (int hf = 0; hf < 2; hf++) {
-            const unsigned long long em = __ballot(passed[hf] != 0xffffffffu);
-            if (em) {
-                const uint32_t m = __popcll(em);
-                if (pend + m > kWave) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(a.pass_count, pend);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (lane < pend) a.pass_list[base + lane] = pend_buf[lane];
-                    pend = 0;
-                }
-                if (passed[hf] != 0xffffffffu) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = passed[hf];
-                pend += m;
-            }
-        }
     }
     if (pend) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.pass_count, pend);
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (lane < pend) a.pass_list[base + lane] = pend_buf[lane];
+        if (gl == 0) base = atomicAdd(a.pass_count, pend);
+        base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
+        for (uint32_t i = gl; i < pend; i += GS) a.pass_list[base + i] = pend_buf[i];
     }
     unsigned long long v64 = gl == 0 ? verified : 0, w64 = gl == 0 ? wbytes : 0;
     for (int d = 32; d > 0; d >>= 1) {
@@ -2016,7 +2049,7 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
 void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
     // persistent 16-lane groups, two candidates per group: one resident generation of blocks pulls the worklist
 #define SW_CASE(RR)                                                                                                      \
-    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 2 : kSwOcc)))), \
+    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 3 : kSwOcc)))), \
                        dim3(256), 0, s, ix, a)
     if (max_len <= 64) SW_CASE(4);
     else if (max_len <= 96) SW_CASE(6);

@@ -41,6 +41,8 @@ struct EvalArgs {
     uint32_t* pass_count = nullptr;
     uint32_t* next_list = nullptr;
     uint32_t* next_count = nullptr;
+    uint32_t flags = 0;  // k_sw_pairs, for measurements: bit 0 skips the diagonal lower bound (MTSV_SW_DIAG=0),
+                         // bit 2 computes it but never acts on it
 };
 
 constexpr uint32_t kMaxReadLen = 512;  // 16 lanes x 32 read rows per lane in k_evaluate

@@ -1,6 +1,7 @@
 """-m gpu parity tests proper: the HIP path, called through the C ABI, against the CPU oracle on
 the same seeded inputs.  Bit-exact: every field of every hit, in the reference's order."""
 import os
+import random
 
 import numpy as np
 import pytest
@@ -339,6 +340,51 @@ def medium():
     ix.to_device(0)
     bases, off = M.synth_reads(ix, seed=4242, n_reads=400_000, read_len=150)
     return ix, bases, off
+
+
+@pytest.mark.parametrize("max_len", [60, 96, 128, 150, 200, 253])
+def test_prefilter_shortcuts_for_every_row_count(tricky, max_len):
+    """Every k_sw_pairs<R> instantiation (R is chosen from the longest read of the batch) with all three
+    ways a candidate leaves the prefilter: decided on the seed diagonal without a sweep (substitutions
+    only), passed or failed by the sweep (indels, junk), rejected by the N count.  Mixed lengths in one
+    batch, both evaluation orders, hits and work counters against the oracle."""
+    ix, orc, _ = tricky
+    entries, gene, unit = helpers.tricky_db()
+    texts = [e[2].upper() for e in entries if len(e[2]) > max_len + 50]
+    rng = random.Random(max_len)
+    reads = []
+    for i in range(700):
+        L = max_len if i % 3 == 0 else rng.randrange(max(20, max_len // 3), max_len + 1)
+        src = gene if i % 2 == 0 and len(gene) > L else rng.choice(texts)
+        st = rng.randrange(0, len(src) - L)
+        r = bytearray(src[st:st + L])
+        kind = i % 5
+        if kind in (0, 1):        # substitutions only: the diagonal decides
+            for _ in range(rng.randrange(0, int(L * 0.13) + 3)):
+                r[rng.randrange(L)] = rng.choice(b"ACGT")
+        elif kind == 2:           # indels: needs the sweep
+            r = bytearray(helpers.mutate(rng, bytes(r), rng.randrange(1, 8)))[:max_len]
+        elif kind == 3:           # N-rich
+            for _ in range(rng.randrange(0, L // 4)):
+                r[rng.randrange(L)] = ord("N")
+        r = bytes(r)
+        reads.append(r if rng.random() < 0.5 else helpers.revcomp(r))
+    assert max(map(len, reads)) == max_len
+    mp, op = both_params()
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want, ctr = orc.bin_batch(bases, off, op, threads=8)
+    assert len(want) > 300
+    b = M.Batch(ix, 0, len(reads), len(bases))
+    b.upload(bases, off)
+    for mode in (0, 1, 0):
+        b.set_verify_mode(mode)
+        b.run(mp)
+        assert_same_hits(b.download(), want)
+        st = b.stats()
+        if mode == 0:
+            assert (st["n_verified"], st["window_bytes"]) == (ctr["n_sw"], ctr["W"])
+    b.close()
 
 
 def test_lanes_do_not_change_hits_or_counters(medium, monkeypatch):
