@@ -973,10 +973,10 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
             if (phase == PH_FETCH) {
                 if (loc == loc_end) {  // dynamic scheduling: chains of failing candidates make items uneven
                     uint32_t base = 0;
-                    if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
+                    if (gl == 0) base = atomicAdd(a.wl_cursor, 16u);  // see k_sw_pairs: claims of 4 are atomic-bound
                     base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
                     loc = min(base, n_work);
-                    loc_end = min(base + 4, n_work);
+                    loc_end = min(base + 16, n_work);
                 }
                 if (loc < loc_end) {
                     g = a.worklist[loc++];
@@ -1272,14 +1272,15 @@ constexpr int kSwOcc = MTSV_SW_OCC;  // resident workgroups of k_sw_pairs per CU
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
 constexpr uint32_t kDecide = 32;  // columns between decision points after the two scheduled ones
 
-constexpr uint32_t kPend = 32;  // passed candidates a group of k_sw_pairs buffers before one atomic
+constexpr uint32_t kPend = 32;   // passed candidates a group of k_sw_pairs buffers before one atomic
+constexpr uint32_t kClaim = 32;  // work items a group of k_sw_pairs claims with one atomic, at most
 
 template <int R>
 __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     constexpr int GS = 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
     __shared__ uint32_t pend_all[256 / GS][kPend];  // a group's passed candidates, flushed with one atomic per kPend
-    __shared__ uint32_t meta_all[256 / GS][4][8];         // the group's claimed work items, staged by lanes 0..3
+    __shared__ uint32_t meta_all[256 / GS][kClaim][8];    // the group's claimed work items, staged by its lanes
     const uint32_t lane = lane_id();
     const uint32_t gl = lane & (GS - 1);
     uint32_t* pend_buf = pend_all[threadIdx.x / GS];
@@ -1300,9 +1301,12 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
     const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
                                                : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
     const uint32_t ONE = 0x00010001u, TWO = 0x00020002u;
+    // items per claim: large enough that the claims do not bound the kernel, small enough that the last
+    // claims of the launch stay balanced (about eight claims per group)
+    const uint32_t chunk = min(max(n_work / (gridDim.x * (256 / GS) * 8u), 4u), kClaim);
 
     uint32_t phase = PH_FETCH;
-    uint32_t loc = 0, loc_end = 0;  // position inside the claimed slice of <= 4 items
+    uint32_t loc = 0, loc_end = 0;  // position inside the claimed slice
     // per-half state; index 0 = low half
     uint32_t st[2] = {HF_EMPTY, HF_EMPTY};
     uint32_t g[2] = {0, 0}, o[2] = {0, 0}, Wn[2] = {0, 0};
@@ -1349,20 +1353,22 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         wf |= 1u << hf;
                     } else if (!(gf & F_DRAINED)) {
                         if (loc == loc_end) {
+                            // One atomic per `chunk` items: atomics on one address complete at ~11 ns each on
+                            // this chip, so 4 items per claim put a floor of 55 ms under 20 M work items.
                             uint32_t base = 0;
-                            if (gl == 0) base = atomicAdd(a.wl_cursor, 4u);
+                            if (gl == 0) base = atomicAdd(a.wl_cursor, chunk);
                             base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
                             const uint32_t first = min(base, n_work);
                             loc = 0;
-                            loc_end = min(base + 4, n_work) - first;
-                            // lanes 0..3 of the group walk the dependent loads of one item each, side by side
-                            if (gl < loc_end) {
-                                const uint32_t gi = a.worklist[first + gl];
+                            loc_end = min(base + chunk, n_work) - first;
+                            // the lanes of the group walk the dependent loads of one item each, side by side
+                            for (uint32_t i = gl; i < loc_end; i += GS) {
+                                const uint32_t gi = a.worklist[first + i];
                                 const uint32_t rs = a.cand_rs[gi];
                                 const uint4 c = a.cand[gi];
                                 const uint32_t r_ = a.r0 + (rs >> 1);
                                 const uint32_t b0 = a.read_off[r_];
-                                uint32_t* m = meta + gl * 8;
+                                uint32_t* m = meta + i * 8;
                                 m[0] = gi;
                                 m[1] = c.x;
                                 m[2] = c.y;
