@@ -77,6 +77,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     if (!parent) {
         dev_alloc(&d_bases, max_bases + 64, &bytes);  // k_search reads up to 36 bytes past a seed start with dword loads
         dev_alloc(&d_read_off, max_reads + 1, &bytes);
+        dev_alloc(&d_codes, max_bases + 64, &bytes);  // normalised copy of d_bases, rewritten by every run()
     }
     dev_alloc(&d_strand_hits, ns + 1, &bytes);
     dev_alloc(&d_strand_nseeds, ns, &bytes);
@@ -121,6 +122,7 @@ Batch::~Batch() {
                     (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_heavy_list})
         (void)hipFree(p);
     (void)hipFree(d_bases2);
+    (void)hipFree(d_codes);
     for (int b = 0; b < 2; b++) {
         if (h_stage_bases[b]) (void)hipHostFree(h_stage_bases[b]);
         if (h_stage_off[b]) (void)hipHostFree(h_stage_off[b]);
@@ -225,14 +227,15 @@ void Batch::end_run() {
 
 void Batch::run(const mtsv_params& p) {
     begin_run(p);
-    run_range(p, d_bases, d_read_off, n_reads, max_len, 0);
+    run_range(p, d_bases, d_codes, d_read_off, h_read_off.data(), n_reads, max_len, 0);
     end_run();
 }
 
 // A resident range of reads, split over the lanes; the hits stay in the lanes, `segments` records them in
-// read order.
-void Batch::run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n, uint32_t range_max_len,
-                      uint64_t read_base) {
+// read order.  raw != nullptr: the range is still ASCII in `raw` and each chunk normalises its bytes into
+// `sb` first (h_off = host copy of the range's n + 1 offsets); raw == nullptr: `sb` already holds codes.
+void Batch::run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, const uint32_t* so, const uint32_t* h_off, uint64_t n,
+                      uint32_t range_max_len, uint64_t read_base) {
     std::vector<Batch*> ls{this};
     for (auto& l : extra) ls.push_back(l.get());
     // Chunks of at most ws_reads reads, handed to the lanes from a shared counter: after the first chunk the
@@ -251,6 +254,8 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             if (c >= n_chunks) return;
             const uint64_t a = std::min(n, c * per), b = std::min(n, (c + 1) * per);
             const uint64_t before = lane->n_hits_total;
+            // base normalisation (binner.rs:88-100) of this chunk's bytes: raw -> codes, on the lane's stream
+            if (raw) launch_normalise(lane->stream, raw, sb, h_off[a], h_off[b]);
             lane->run_slice(p, sb, so + a, b - a, range_max_len, read_base + a);
             segs[c] = Segment{lane, before, lane->n_hits_total - before};
         }
@@ -521,6 +526,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     parallel_copy(h_stage_bases[k & 1], bases + first, nb);
                     HIP_CHECK(hipMemcpyAsync(buf_b[k & 1], h_stage_bases[k & 1], nb, hipMemcpyHostToDevice, copy_stream));
                 }
+                launch_normalise(copy_stream, buf_b[k & 1], buf_b[k & 1], 0, nb);  // in place: a slice is consumed once
                 HIP_CHECK(hipMemcpyAsync(buf_o[k & 1], off32, (cnt + 1) * 4, hipMemcpyHostToDevice, copy_stream));
                 const double t1 = now_s();
                 HIP_CHECK(hipStreamSynchronize(copy_stream));
@@ -560,7 +566,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
             }
             max_len = std::max(max_len, sl.max_len);
             const double t0 = now_s();
-            run_range(p, buf_b[k & 1], buf_o[k & 1], sl.end - sl.begin, sl.max_len, sl.begin);
+            run_range(p, nullptr, buf_b[k & 1], buf_o[k & 1], nullptr, sl.end - sl.begin, sl.max_len, sl.begin);
             if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3);
             {
                 std::lock_guard<std::mutex> lk(mu);

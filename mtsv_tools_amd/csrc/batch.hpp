@@ -32,6 +32,7 @@ struct Batch {
     double run_t0 = 0;
     uint64_t lanes_used = 1;
 
+    uint8_t* d_codes = nullptr;  // run(): normalised copy of d_bases
     uint8_t *d_bases = nullptr, *d_bases2 = nullptr;  // second input buffer: run_host() double-buffers slices
     uint32_t *d_read_off = nullptr, *d_read_off2 = nullptr;
     uint32_t *d_seed_lo = nullptr, *d_seed_cnt = nullptr, *d_seed_pre = nullptr;
@@ -75,8 +76,8 @@ struct Batch {
     void begin_run(const mtsv_params& p);
     void reset_lane();
     void finish_lane();
-    void run_range(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n, uint32_t range_max_len,
-                   uint64_t read_base);
+    void run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, const uint32_t* so, const uint32_t* h_off, uint64_t n,
+                   uint32_t range_max_len, uint64_t read_base);
     void run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n_slice, uint32_t slice_max_len,
                    uint64_t read_base);
     void end_run();

@@ -30,13 +30,35 @@ __device__ inline uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
 // ---------------------------------------------------------------------------------------------
 // strand access: symbol code of position p of strand `strand` of a read (binner.rs:88-100,115)
 // ---------------------------------------------------------------------------------------------
+// (the read buffer holds symbol codes: k_normalise has run over it)
 __device__ inline uint32_t strand_code(const uint8_t* __restrict__ read, uint32_t L, uint32_t strand, uint32_t p) {
-    return strand ? comp_code(base_code(read[L - 1 - p])) : base_code(read[p]);
+    return strand ? comp_code(read[L - 1 - p]) : (uint32_t)read[p];
 }
 
 __device__ inline uint32_t n_seeds_of(uint32_t L, uint32_t K, uint32_t G) {
     // offsets 0, G, 2G, ... < L + 1 - K  (index.rs:284-286); L + 1 < K is trapped as "no seeds"
     return (L >= K) ? (L - K) / G + 1 : 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// K0: base normalisation of the worker closure (binner.rs:88-100), src -> dst (may be the same buffer):
+// A/a C/c G/g T/t -> codes 0..3, every other byte -> N (4).  16 bytes per lane.  Everything
+// downstream reads codes; the reverse complement (binner.rs:115) is applied where a strand is read.
+// ---------------------------------------------------------------------------------------------
+__device__ inline uint32_t fast_code(uint32_t ch);
+__global__ __launch_bounds__(256) void k_normalise(const uint8_t* src, uint8_t* dst, uint64_t n_bytes) {
+    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= n_bytes) return;
+    uint4 v = *reinterpret_cast<const uint4*>(src + i);  // both buffers are 16-byte aligned here and have 64 bytes of slack
+    uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t o = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) o |= fast_code((w[k] >> (8 * q)) & 0xffu) << (8 * q);
+        w[k] = o;
+    }
+    *reinterpret_cast<uint4*>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -91,7 +113,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint32_t bi = k * 4 + q;  // byte index inside the fetched span
-                    uint32_t code = fast_code((w >> (8 * q)) & 0xffu);
+                    uint32_t code = (w >> (8 * q)) & 0xffu;  // already a code (k_normalise)
                     if (strand) code = comp_code(code);
                     const uint32_t pos = strand ? (K - 1 - bi) : bi;  // strand-order position of this byte
                     if (bi < K) {
@@ -1429,7 +1451,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             const uint32_t kf = (uint32_t)r, kr = (uint32_t)(R - 1 - r);  // byte of this row in raw[]
                             const uint32_t bf = (raw[hf][kf >> 2] >> (8 * (kf & 3))) & 0xffu;
                             const uint32_t br = (raw[hf][kr >> 2] >> (8 * (kr & 3))) & 0xffu;
-                            uint32_t code = fast_code(strands[hf] ? br : bf);
+                            uint32_t code = strands[hf] ? br : bf;  // already a code (k_normalise)
                             if (strands[hf]) code = comp_code(code);
                             if (p < 0) code = 6u;
                             nn += code == kCodeN;
@@ -1781,7 +1803,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
 #pragma unroll
                             for (int q = 0; q < 4; q++) {
                                 const int bit_i = 4 * j + q;
-                                const uint32_t code = fast_code((four >> (8 * q)) & 0xffu);
+                                const uint32_t code = (four >> (8 * q)) & 0xffu;  // already a code (k_normalise)
                                 const uint32_t bit = 1u << bit_i;
                                 const bool real = q0 + bit_i >= 0;
                                 mA |= (real && code == 0) ? bit : 0u;
@@ -1956,6 +1978,13 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t n_strands, uint64_t r0,
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end) {
+    begin &= ~15ull;  // whole 16-byte groups (a neighbouring range may write the same codes into a shared group)
+    if (end <= begin) return;
+    const uint64_t n = end - begin;
+    hipLaunchKernelGGL(k_normalise, dim3(cdiv((n + 15) / 16, 256)), dim3(256), 0, s, src + begin, dst + begin, n);
+}
 
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt) {

@@ -47,6 +47,8 @@ struct EvalArgs {
 
 constexpr uint32_t kMaxReadLen = 512;  // 16 lanes x 32 read rows per lane in k_evaluate
 
+// base normalisation of bytes [begin, end) of a read buffer, src -> dst (may be equal): every other kernel expects codes
+void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end);
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt);
 void launch_thin(hipStream_t s, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, uint32_t max_ns, uint32_t K,
