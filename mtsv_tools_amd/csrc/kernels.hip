@@ -97,11 +97,38 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
         // packed codes: symbol i of the seed (strand order) at bits [3i, 3i+3) of c_lo (i < 21) / c_hi
         uint64_t c_lo = 0, c_hi = 0;
         const bool packed = K <= kMaxPackedSeed;
-        if (packed) {
-            // forward strand: bytes [off, off+K); reverse strand: bytes [L-off-K, L-off) reversed + complemented
-            const uint32_t s0 = b0 + (strand ? L - off - K : off);
-            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
-            const uint32_t w0 = s0 >> 2, sh = s0 & 3;
+        // forward strand: bytes [off, off+K); reverse strand: bytes [L-off-K, L-off) reversed + complemented
+        const uint32_t s0 = b0 + (strand ? L - off - K : off);
+        const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
+        const uint32_t w0 = s0 >> 2, sh = s0 & 3;
+        if (K <= 21) {
+            // up to 21 symbols fit one 64-bit word; four codes of a dword are squeezed to 12 bits with shifts
+            // (codes < 8), the reverse strand is complemented bytewise and turned round by one 64-bit bit
+            // reversal (after swapping bit 0 and bit 2 of every code, which the reversal swaps back)
+            uint32_t d[7];
+#pragma unroll
+            for (int k = 0; k < 7; k++) d[k] = (uint32_t)(4 * k) < K + 4 ? b32[w0 + k] : 0u;
+            uint64_t c = 0;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+                if (strand) {
+                    const uint32_t m = (~w >> 2) & 0x01010101u;  // codes below 4: x -> 3 - x = x ^ 3
+                    w ^= m | (m << 1);
+                    const uint32_t t = (w ^ (w >> 2)) & 0x01010101u;
+                    w ^= t | (t << 2);
+                }
+                const uint32_t x = (w | (w >> 5)) & 0x003f003fu;
+                const uint32_t p12 = (x | (x >> 10)) & 0xfffu;
+                if (12 * k < 64) c |= (uint64_t)p12 << (12 * k);
+            }
+            c &= (K < 21 ? (1ull << (3 * K)) : (1ull << 63)) - 1;
+            if (strand) {
+                const uint64_t rv = ((uint64_t)__builtin_bitreverse32((uint32_t)c) << 32) | __builtin_bitreverse32((uint32_t)(c >> 32));
+                c = rv >> (64 - 3 * K);
+            }
+            c_lo = c;
+        } else if (packed) {
             uint32_t d[9];
             const uint32_t nd = (K + 3) / 4;  // dwords that hold seed bytes (wave-uniform)
 #pragma unroll
@@ -134,10 +161,24 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
         if (ix.kmer_tab && K >= ix.kmer_k) {
             uint32_t idx = 0;
             bool acgt = true;
-            for (uint32_t t = 0; t < ix.kmer_k; t++) {
-                uint32_t a = sym(K - ix.kmer_k + t);
-                acgt &= a < 4;
-                idx = (idx << 2) | (a & 3);
+            if (K <= 21) {
+                const uint32_t kk = ix.kmer_k;  // <= 15
+                const uint64_t sub = c_lo >> (3 * (K - kk));  // the last kk symbols, first of them lowest
+                const uint32_t s_lo = (uint32_t)sub & 0x3fffffffu, s_hi = (uint32_t)(sub >> 30) & 0x7fffu;
+                acgt = ((s_lo & 0x24924924u) | (s_hi & 0x4924u)) == 0;  // no code has bit 2 set: all of A C G T
+                uint32_t idx15 = 0;  // symbol t at bits [2(14-t), 2(14-t)+2): the table's order, first symbol highest
+#pragma unroll
+                for (int t = 0; t < 15; t++) {
+                    const uint32_t a = t < 10 ? (s_lo >> (3 * t)) & 3u : (s_hi >> (3 * (t - 10))) & 3u;
+                    idx15 |= a << (2 * (14 - t));
+                }
+                idx = idx15 >> (2 * (15 - kk));
+            } else {
+                for (uint32_t t = 0; t < ix.kmer_k; t++) {
+                    uint32_t a = sym(K - ix.kmer_k + t);
+                    acgt &= a < 4;
+                    idx = (idx << 2) | (a & 3);
+                }
             }
             if (acgt) {
                 uint2 iv = ix.kmer_tab[idx];
