@@ -1437,8 +1437,11 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                                 m[2] = c.y;
                                 m[3] = a.strand_off[rs];
                                 m[4] = b0;
-                                m[5] = a.read_off[r_ + 1] - b0;
-                                m[6] = rs & 1;
+                                const uint32_t Li = a.read_off[r_ + 1] - b0;
+                                const uint32_t EDi = (uint32_t)ceil((double)Li * a.edit_rate);  // index.rs:281-282
+                                m[5] = Li;
+                                // strand, usize wrap of index.rs:406 (2*ED > L: nothing can pass), ED, threshold L - 2*ED
+                                m[6] = (rs & 1) | (2ull * EDi > (uint64_t)Li ? 2u : 0u) | ((EDi & 0xffu) << 8) | (((Li - 2 * EDi) & 0xffu) << 16);
                             }
                         }
                         if (loc == loc_end) {
@@ -1452,7 +1455,8 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             o[hf] = m[3];
                             b0s[hf] = m[4];
                             geo = (geo & ~(0xffu << (8 * hf))) | ((m[5] & 0xffu) << (8 * hf));
-                            strands[hf] = m[6];
+                            strands[hf] = m[6];  // bit 0 strand, bit 1 wrapped, bits 8-15 ED, 16-23 threshold
+                            geo = (geo & ~(0xffu << (16 + 8 * hf))) | (((m[6] >> 16) & 0xffu) << (16 + 8 * hf));
                             wf |= 5u << hf;
                         }
                     }
@@ -1463,7 +1467,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             // aligned dword loads + v_alignbyte; byte k of raw[] is read byte s0 + k
                             const int pad = (int)(GS * R) - (int)Lh(hf);
                             const int p0 = (int)(gl * R) - pad;  // read position of row 0, < 0 for padding rows
-                            const int s0 = strands[hf] ? (int)Lh(hf) - 1 - p0 - (R - 1) : p0;
+                            const int s0 = (strands[hf] & 1u) ? (int)Lh(hf) - 1 - p0 - (R - 1) : p0;
                             const long long byte0 = (long long)b0s[hf] + s0;
                             const long long w0 = byte0 >> 2;
                             const uint32_t sh = (uint32_t)(byte0 & 3);
@@ -1481,9 +1485,8 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                 for (int hf = 0; hf < 2; hf++) {
                     if (!(wf & (1u << hf))) continue;
                     if (wf & (4u << hf)) {
-                        const uint32_t ED = (uint32_t)ceil((double)Lh(hf) * a.edit_rate);  // index.rs:281-282
-                        const bool wrapped = 2ull * ED > (uint64_t)Lh(hf);                  // usize wrap of index.rs:406
-                        geo = (geo & ~(0xffu << (16 + 8 * hf))) | (((Lh(hf) - 2 * ED) & 0xffu) << (16 + 8 * hf));
+                        const uint32_t ED = (strands[hf] >> 8) & 0xffu;
+                        const bool wrapped = (strands[hf] & 2u) != 0;
                         const int pad = (int)(GS * R) - (int)Lh(hf);
                         int nn = 0;
 #pragma unroll
@@ -1492,8 +1495,8 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             const uint32_t kf = (uint32_t)r, kr = (uint32_t)(R - 1 - r);  // byte of this row in raw[]
                             const uint32_t bf = (raw[hf][kf >> 2] >> (8 * (kf & 3))) & 0xffu;
                             const uint32_t br = (raw[hf][kr >> 2] >> (8 * (kr & 3))) & 0xffu;
-                            uint32_t code = strands[hf] ? br : bf;  // already a code (k_normalise)
-                            if (strands[hf]) code = comp_code(code);
+                            uint32_t code = (strands[hf] & 1u) ? br : bf;  // already a code (k_normalise)
+                            if (strands[hf] & 1u) code = comp_code(code);
                             if (p < 0) code = 6u;
                             nn += code == kCodeN;
                             qc2[r] = hf ? ((qc2[r] & 0x0000ffffu) | (code << 17)) : ((qc2[r] & 0xffff0000u) | (code << 1));
