@@ -986,7 +986,7 @@ __device__ inline uint4 load16(const uint8_t* __restrict__ text, uint32_t n, uin
     return r;
 }
 
-enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2, PH_CHAIN = 3 };
+enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2, PH_CHAIN = 3, PH_WAIT = 4 };
 
 // One work item = the first candidate of a TaxId of a strand (index into cand[]).  When it fails, the
 // group moves on to the next candidate of that TaxId in rank order (same read rows, new window), which
@@ -1392,6 +1392,13 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
     }
 
     for (;;) {
+        // The four groups of a wavefront fetch together: a group whose pair is decided waits until its
+        // siblings' sweeps are over.  A fetch executed for one group costs the wavefront as many
+        // instructions as one executed for all four, and fetching is ~40 % of this kernel's instructions.
+        {
+            const bool sweeping = __any(phase == PH_SWEEP);
+            if (phase == PH_WAIT && !sweeping) phase = PH_FETCH;
+        }
         if (__builtin_expect(phase == PH_FETCH, 0)) {
             uint8_t* rings = &ring_all[threadIdx.x / GS][0][0];
             uint32_t* meta = &meta_all[threadIdx.x / GS][0][0];
@@ -1716,7 +1723,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                 }
                 st[hf] = HF_EMPTY;
             }
-            phase = PH_FETCH;
+            phase = PH_WAIT;
         }
     }
     if (pend) {
