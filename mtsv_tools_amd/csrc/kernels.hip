@@ -1540,25 +1540,59 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         bool decided = false;
                         if (EDq + Lq <= lim && !(a.flags & 1u)) {
                             const int pad = (int)(GS * R) - (int)Lq;
-                            // the lane's R window symbols on that diagonal: aligned dwords + v_alignbyte
-                            const int base = (int)EDq + (int)(gl * R) - pad;  // negative for padding rows (ignored below)
+                            // the lane's R window symbols on that diagonal (and its two neighbours): aligned dwords +
+                            // v_alignbyte; sy[d] faces read position p with window column ED + p + d - 1
+                            const int base = (int)EDq + (int)(gl * R) - pad - 1;  // negative for padding rows (ignored below)
                             const uint32_t* ring32 = reinterpret_cast<const uint32_t*>(rings + hf * kRingP);
-                            constexpr int RD = (R + 3) / 4;
-                            uint32_t dd[RD + 1], sy[RD];
+                            constexpr int RD = (R + 2 + 3) / 4 + 1;
+                            uint32_t dd[RD + 1];
 #pragma unroll
                             for (int k = 0; k <= RD; k++) dd[k] = ring32[(uint32_t)((base >> 2) + k) & (kRingP / 4 - 1)];
+                            int mm[3] = {0, 0, 0};
 #pragma unroll
-                            for (int k = 0; k < RD; k++) sy[k] = __builtin_amdgcn_alignbyte(dd[k + 1], dd[k], (uint32_t)base & 3u);
-                            int mm = 0;
+                            for (int d = 0; d < 3; d++) {
+                                const int bd = base + d;
+                                const int skip = (bd >> 2) - (base >> 2);  // 0 or 1 dwords further into dd[]
+                                uint32_t sy[(R + 3) / 4];
 #pragma unroll
-                            for (int r = 0; r < R; r++) {
-                                const int p = (int)(gl * R + r) - pad;
-                                const uint32_t sym = (sy[r >> 2] >> (8 * (r & 3))) & 0xffu;
-                                const uint32_t code = (qc2[r] >> (16 * hf + 1)) & 7u;
-                                mm += (p >= 0 && code != sym) ? 1 : 0;
+                                for (int k = 0; k < (R + 3) / 4; k++) {
+                                    const uint32_t lo_ = skip ? dd[k + 1] : dd[k], hi_ = skip ? dd[k + 2] : dd[k + 1];
+                                    sy[k] = __builtin_amdgcn_alignbyte(hi_, lo_, (uint32_t)bd & 3u);
+                                }
+#pragma unroll
+                                for (int r = 0; r < R; r++) {
+                                    const int p = (int)(gl * R + r) - pad;
+                                    const uint32_t sym = (sy[r >> 2] >> (8 * (r & 3))) & 0xffu;
+                                    const uint32_t code = (qc2[r] >> (16 * hf + 1)) & 7u;
+                                    mm[d] += (p >= 0 && code != sym) ? 1 : 0;
+                                }
                             }
-                            mm = row_sum16(mm);
-                            decided = (uint32_t)mm <= EDq && !(a.flags & 4u);
+                            const int mm0 = row_sum16(mm[1]);
+                            decided = (uint32_t)mm0 <= EDq && !(a.flags & 4u);
+                            // One gap: read rows of the lanes below s on the diagonal, the rest on a neighbouring one
+                            // (a base missing from the read, or an extra one), joined by a gap of one.  That alignment
+                            // scores at least L - 2 - 2*mismatches, so mismatches <= ED - 1 still proves the
+                            // threshold; the split s is tried at every lane boundary with two row scans.
+                            if (!decided && EDq >= 1 && EDq + Lq + 1 <= lim) {
+                                int pre = mm[1];  // inclusive prefix sum over the lanes of the row
+                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, true);   // row_shr:1
+                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, true);   // row_shr:2
+                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, true);   // row_shr:4
+                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, true);   // row_shr:8
+                                int best_mm = 0x7fffffff;
+#pragma unroll
+                                for (int d = 0; d < 3; d += 2) {
+                                    int suf = mm[d];  // inclusive suffix sum
+                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x101, 0xf, 0xf, true);  // row_shl:1
+                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x102, 0xf, 0xf, true);  // row_shl:2
+                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x104, 0xf, 0xf, true);  // row_shl:4
+                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x108, 0xf, 0xf, true);  // row_shl:8
+                                    // split before this lane: lanes < gl on the diagonal (pre - own), this lane and above on d
+                                    best_mm = min(best_mm, pre - mm[1] + suf);
+                                }
+                                best_mm = -row_max16(-best_mm);
+                                decided = best_mm <= (int)EDq - 1 && !(a.flags & 4u);
+                            }
                         }
                         if (decided) {
                             pass_push(g[hf]);  // its edit distance is k_edit_myers' business (index.rs:407-410)
