@@ -84,24 +84,26 @@ __global__ void k_kmer_level1(DevIndexView ix, uint2* __restrict__ tab) {
 // level j from level j-1: interval(aP) = LF-step(a, interval(P)); index(aP) = a*4^(j-1)+index(P)
 __global__ void k_kmer_level(DevIndexView ix, const uint2* __restrict__ prev, uint2* __restrict__ cur,
                              uint32_t prev_entries) {
-    uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (uint64_t)prev_entries * 4) return;
-    uint32_t a = (uint32_t)(t / prev_entries);
-    uint32_t p = (uint32_t)(t % prev_entries);
-    uint2 iv = prev[p];
-    uint32_t lo = 0, hi = 0;
-    if (iv.x < iv.y) {
-        uint32_t b0 = iv.x >> kBlockShift, b1 = iv.y >> kBlockShift;
-        LoadedBlock B0 = load_block(ix.blocks, b0);
-        lo = less_of(ix, a) + block_rank(B0, a, b0, iv.x & (kBlockRows - 1), ix.sentinel_row);
-        if (b1 == b0) {
-            hi = less_of(ix, a) + block_rank(B0, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
-        } else {
-            LoadedBlock B1 = load_block(ix.blocks, b1);
-            hi = less_of(ix, a) + block_rank(B1, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
+    // grid-stride: the last level of a 16-mer table has 2^32 entries, more than one launch may have threads
+    const uint64_t total = (uint64_t)prev_entries * 4, stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
+        uint32_t a = (uint32_t)(t / prev_entries);
+        uint32_t p = (uint32_t)(t % prev_entries);
+        uint2 iv = prev[p];
+        uint32_t lo = 0, hi = 0;
+        if (iv.x < iv.y) {
+            uint32_t b0 = iv.x >> kBlockShift, b1 = iv.y >> kBlockShift;
+            LoadedBlock B0 = load_block(ix.blocks, b0);
+            lo = less_of(ix, a) + block_rank(B0, a, b0, iv.x & (kBlockRows - 1), ix.sentinel_row);
+            if (b1 == b0) {
+                hi = less_of(ix, a) + block_rank(B0, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
+            } else {
+                LoadedBlock B1 = load_block(ix.blocks, b1);
+                hi = less_of(ix, a) + block_rank(B1, a, b1, iv.y & (kBlockRows - 1), ix.sentinel_row);
+            }
         }
+        cur[t] = make_uint2(lo, hi);
     }
-    cur[t] = make_uint2(lo, hi);
 }
 
 template <class F>
@@ -285,13 +287,17 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
         v.sa_full = di->d_sa_full;
     }
     if (!(flags & 2u /* MTSV_DEV_NO_KMER_TABLE */)) {
-        // table size ~ index size: 4^k entries of 8 B for 4^k <= n, capped at k = 15 (8 GiB)
+        // table size ~ index size: 4^k entries of 8 B for 4^k <= 2n, at most k = 16 (32 GiB: every symbol of the
+        // table saves a dependent pair of rank-block gathers per seed), and only if it fits the free HBM twice over
         uint32_t k = 1;
-        while (k < 15 && (1ull << (2 * (k + 1))) <= (uint64_t)n) k++;
+        while (k < 16 && (1ull << (2 * (k + 1))) <= 2 * (uint64_t)n) k++;
         if (const char* e = getenv("MTSV_KMER_K")) {
             int kk = atoi(e);
-            if (kk >= 1 && kk <= 15) k = (uint32_t)kk;
+            if (kk >= 1 && kk <= 16) k = (uint32_t)kk;
         }
+        size_t free_b = 0, total_b = 0;
+        HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
+        while (k > 1 && (10ull << (2 * k)) * 2 > (uint64_t)free_b) k--;  // table + the previous level while building
         uint64_t entries = 1ull << (2 * k);
         uint2 *ta = nullptr, *tb = nullptr;
         HIP_CHECK(hipMalloc((void**)&ta, entries * 8));
@@ -303,10 +309,10 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
         uint32_t prev_entries = 4;
         for (uint32_t lvl = 2; lvl <= k; lvl++) {
             uint64_t total = (uint64_t)prev_entries * 4;
-            hipLaunchKernelGGL(k_kmer_level, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, 0, v, cur, oth,
+            hipLaunchKernelGGL(k_kmer_level, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 1u << 22)), dim3(256), 0, 0, v, cur, oth,
                                prev_entries);
             std::swap(cur, oth);
-            prev_entries = (uint32_t)total;
+            prev_entries = (uint32_t)std::min<uint64_t>(total, 0xffffffffull);  // (only read again if another level follows)
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());

@@ -162,17 +162,17 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
             uint32_t idx = 0;
             bool acgt = true;
             if (K <= 21) {
-                const uint32_t kk = ix.kmer_k;  // <= 15
+                const uint32_t kk = ix.kmer_k;  // <= 16
                 const uint64_t sub = c_lo >> (3 * (K - kk));  // the last kk symbols, first of them lowest
-                const uint32_t s_lo = (uint32_t)sub & 0x3fffffffu, s_hi = (uint32_t)(sub >> 30) & 0x7fffu;
-                acgt = ((s_lo & 0x24924924u) | (s_hi & 0x4924u)) == 0;  // no code has bit 2 set: all of A C G T
-                uint32_t idx15 = 0;  // symbol t at bits [2(14-t), 2(14-t)+2): the table's order, first symbol highest
+                const uint32_t s_lo = (uint32_t)sub & 0x3fffffffu, s_hi = (uint32_t)(sub >> 30) & 0x3ffffu;
+                acgt = ((s_lo & 0x24924924u) | (s_hi & 0x24924u)) == 0;  // no code has bit 2 set: all of A C G T
+                uint32_t idx16 = 0;  // symbol t at bits [2(15-t), 2(15-t)+2): the table's order, first symbol highest
 #pragma unroll
-                for (int t = 0; t < 15; t++) {
+                for (int t = 0; t < 16; t++) {
                     const uint32_t a = t < 10 ? (s_lo >> (3 * t)) & 3u : (s_hi >> (3 * (t - 10))) & 3u;
-                    idx15 |= a << (2 * (14 - t));
+                    idx16 |= a << (2 * (15 - t));
                 }
-                idx = idx15 >> (2 * (15 - kk));
+                idx = kk >= 16 ? idx16 : idx16 >> (2 * (16 - kk));
             } else {
                 for (uint32_t t = 0; t < ix.kmer_k; t++) {
                     uint32_t a = sym(K - ix.kmer_k + t);

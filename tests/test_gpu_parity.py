@@ -342,6 +342,29 @@ def medium():
     return ix, bases, off
 
 
+@pytest.mark.parametrize("k", ["16", "11"])
+def test_kmer_table_width_does_not_change_hits(tricky, monkeypatch, k):
+    """The k-mer interval table replaces the first k backward-search steps of a seed; 16 is the widest
+    (32 GiB, chosen by itself for the 10 GB index), and a table as wide as the seed minus two leaves two
+    FM steps.  Hits and counters must not depend on it."""
+    entries, _, _ = helpers.tricky_db()
+    ix2 = M.MGIndex.build(entries, threads=4)
+    monkeypatch.setenv("MTSV_KMER_K", k)
+    ix2.to_device(0)
+    monkeypatch.delenv("MTSV_KMER_K")
+    _, orc, reads = tricky
+    mp, op = both_params()
+    bases, off = helpers.reads_to_batch(reads)
+    want, ctr = orc.bin_batch(bases, off, op, threads=8)
+    b = M.Batch(ix2, 0, len(reads), len(bases))
+    b.upload(bases, off)
+    b.run(mp)
+    assert_same_hits(b.download(), want)
+    assert b.stats()["n_seed_hits"] == ctr["H"]
+    b.close()
+    ix2.close()
+
+
 @pytest.mark.parametrize("max_len", [60, 96, 128, 150, 200, 253])
 def test_prefilter_shortcuts_for_every_row_count(tricky, max_len):
     """Every k_sw_pairs<R> instantiation (R is chosen from the longest read of the batch) with all three
