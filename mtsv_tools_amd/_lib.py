@@ -131,7 +131,10 @@ def set_build_device(device):
 def default_params(**over):
     p = Params()
     lib().mtsv_params_default(C.byref(p))
+    names = {f[0] for f in Params._fields_}
     for k, v in over.items():
+        if k not in names:
+            raise AttributeError(f"no such parameter: {k}")
         setattr(p, k, -1 if v is None else v)
     return p
 

@@ -97,7 +97,12 @@ def lib():
 def default_params(**over):
     p = Params()
     lib().orc_default_params(C.byref(p))
+    names = {f[0] for f in Params._fields_}
     for k, v in over.items():
+        if k == "seed_interval":  # the product's name for the same CLI flag (--seed-interval)
+            k = "seed_gap"
+        if k not in names:
+            raise AttributeError(f"no such parameter: {k}")
         if v is None:
             v = -1
         setattr(p, k, v)
