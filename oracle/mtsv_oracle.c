@@ -383,7 +383,7 @@ uint64_t orc_brute_find(const orc_index *ix, const uint8_t *pat, uint64_t len, u
 /* ------------------------------------------------------------------------------------------ */
 uint32_t orc_min_edit_distance(const uint8_t *p, uint64_t m, const uint8_t *t, uint64_t n) {
     uint64_t row_mult = n + 1;
-    uint32_t *d = malloc((m + 1) * row_mult * sizeof(uint32_t));
+    uint32_t *d = calloc((m + 1) * row_mult, sizeof(uint32_t));
     for (uint64_t i = 0; i < row_mult; i++) d[i] = 0;                 /* align.rs:37-41 */
     for (uint64_t row = 1; row <= m; row++) d[row * row_mult] = (uint32_t)row; /* :44-48 */
     for (uint64_t row = 1; row <= m; row++)
