@@ -123,6 +123,8 @@ Batch::~Batch() {
         (void)hipFree(p);
     (void)hipFree(d_bases2);
     (void)hipFree(d_codes);
+    if (h_hits_stage) (void)hipHostFree(h_hits_stage);
+    if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
     for (int b = 0; b < 2; b++) {
         if (h_stage_bases[b]) (void)hipHostFree(h_stage_bases[b]);
         if (h_stage_off[b]) (void)hipHostFree(h_stage_off[b]);
@@ -186,6 +188,7 @@ void Batch::begin_run(const mtsv_params& p) {
     segments.clear();
     total_hits = 0;
     lanes_used = 1;
+    staged_valid = false;
     run_t0 = now_s();
     reset_lane();
     for (auto& l : extra) {
@@ -555,6 +558,8 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
         n_reads = n;
         max_len = 0;
         begin_run(p);
+        if (!copy_stream2) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
+        staged_hits = 0;
         for (uint64_t k = 0;; k++) {
             Slice sl;
             {
@@ -566,8 +571,18 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
             }
             max_len = std::max(max_len, sl.max_len);
             const double t0 = now_s();
+            const size_t seg0 = segments.size();
             run_range(p, nullptr, buf_b[k & 1], buf_o[k & 1], nullptr, sl.end - sl.begin, sl.max_len, sl.begin);
             if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3);
+            // this slice's hits start their way to the host (pinned staging) under the next slice's kernels
+            for (size_t si = seg0; si < segments.size(); si++) {
+                const Segment& sg = segments[si];
+                if (!sg.count) continue;
+                stage_reserve(staged_hits + sg.count);
+                HIP_CHECK(hipMemcpyAsync(h_hits_stage + staged_hits, sg.lane->d_hits + sg.offset, sg.count * sizeof(mtsv_hit),
+                                         hipMemcpyDeviceToHost, copy_stream2));
+                staged_hits += sg.count;
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 consumed = k + 1;
@@ -575,6 +590,8 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
             cv.notify_all();
         }
         end_run();
+        HIP_CHECK(hipStreamSynchronize(copy_stream2));
+        staged_valid = staged_hits == total_hits;
     } catch (...) {
         err = std::current_exception();
     }
@@ -587,11 +604,26 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     if (err) std::rethrow_exception(err);
 }
 
+// pinned staging of run_host's hits: grown geometrically, kept for the life of the workspace
+void Batch::stage_reserve(uint64_t n_hits_needed) {
+    if (n_hits_needed <= h_hits_cap) return;
+    HIP_CHECK(hipStreamSynchronize(copy_stream2));
+    const uint64_t ncap = std::max<uint64_t>(std::max<uint64_t>(2 * h_hits_cap, n_hits_needed), 1ull << 20);
+    mtsv_hit* nh = nullptr;
+    HIP_CHECK(hipHostMalloc((void**)&nh, ncap * sizeof(mtsv_hit)));
+    if (staged_hits) memcpy(nh, h_hits_stage, staged_hits * sizeof(mtsv_hit));
+    if (h_hits_stage) (void)hipHostFree(h_hits_stage);
+    h_hits_stage = nh;
+    h_hits_cap = ncap;
+}
+
 void Batch::download(mtsv_hit** hits, uint64_t* n) {
     HIP_CHECK(hipSetDevice(di->device));
     mtsv_hit* h = (mtsv_hit*)malloc(std::max<uint64_t>(total_hits, 1) * sizeof(mtsv_hit));
     if (!h) throw std::runtime_error("nomem: result array");
-    if (total_hits) {
+    if (total_hits && staged_valid) {  // run_host already brought them over: one parallel host copy
+        parallel_copy((uint8_t*)h, (const uint8_t*)h_hits_stage, total_hits * sizeof(mtsv_hit));
+    } else if (total_hits) {
         // fault the fresh pages in from several threads: a D2H copy into untouched malloc memory is
         // page-fault bound (~12 GB/s instead of ~55)
         uint8_t* hb = (uint8_t*)h;

@@ -12,7 +12,10 @@ namespace mtsv {
 struct Batch {
     mtsv_index* ix;
     DeviceIndex* di;
-    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
+    mtsv_hit* h_hits_stage = nullptr;  // pinned: run_host copies every slice's hits here while the next slice runs
+    uint64_t h_hits_cap = 0, staged_hits = 0;
+    bool staged_valid = false;
     uint64_t max_reads, max_bases, hit_cap, hits_cap = 0;
     uint64_t bytes = 0;
     // Lanes: the workspace is cut into n_lanes equal parts, each with its own stream; a resident range of
@@ -75,6 +78,7 @@ struct Batch {
    private:
     void begin_run(const mtsv_params& p);
     void reset_lane();
+    void stage_reserve(uint64_t n_hits_needed);
     void finish_lane();
     void run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, const uint32_t* so, const uint32_t* h_off, uint64_t n,
                    uint32_t range_max_len, uint64_t read_base);
