@@ -486,8 +486,10 @@ int main(int argc, char** argv) {
         return 0;
     }
 
-    FILE* out = fopen(a.results.c_str(), append ? "ab" : "wb");
-    if (!out) {
+    // positional writes from several threads: the result file is written at page-cache speed per thread
+    const int out_fd = ::open(a.results.c_str(), O_WRONLY | O_CREAT | (append ? 0 : O_TRUNC), 0644);
+    off_t out_pos = out_fd >= 0 ? lseek(out_fd, 0, SEEK_END) : 0;
+    if (out_fd < 0) {
         logmsg("ERROR", "Error running query: cannot open results file " + a.results);
         return 2;
     }
@@ -593,18 +595,42 @@ int main(int argc, char** argv) {
             }
             mtsv_hits_free(w->hits);
             bool ok = true;
-            for (unsigned k = 0; k < parts; k++) {
+            for (unsigned k = 0; k < parts; k++)
                 if (rc[k] != MTSV_OK) {
                     if (ok) logmsg("ERROR", "Error running query: " + msg[k]);
                     set_code(2);
                     ok = false;
-                } else if (ok && !failed() && len[k] && fwrite(text[k], 1, len[k], out) != len[k]) {
-                    logmsg("ERROR", "Error writing to result file");
-                    set_code(11);  // binner.rs:136-139
-                    ok = false;
                 }
-                mtsv_free(text[k]);
+            if (ok && !failed()) {
+                std::vector<off_t> at(parts);
+                for (unsigned k = 0; k < parts; k++) {
+                    at[k] = out_pos;
+                    out_pos += (off_t)len[k];
+                }
+                std::vector<char> bad(parts, 0);
+                auto put = [&](unsigned k) {
+                    uint64_t done = 0;
+                    while (done < len[k]) {
+                        ssize_t r = pwrite(out_fd, text[k] + done, len[k] - done, at[k] + (off_t)done);
+                        if (r <= 0) {
+                            bad[k] = 1;
+                            return;
+                        }
+                        done += (uint64_t)r;
+                    }
+                };
+                std::vector<std::thread> th;
+                for (unsigned k = 1; k < parts; k++) th.emplace_back(put, k);
+                put(0);
+                for (auto& t : th) t.join();
+                for (unsigned k = 0; k < parts; k++)
+                    if (bad[k] && ok) {
+                        logmsg("ERROR", "Error writing to result file");
+                        set_code(11);  // binner.rs:136-139
+                        ok = false;
+                    }
             }
+            for (unsigned k = 0; k < parts; k++) mtsv_free(text[k]);
             pool.put(std::move(w->rb));
             if (!ok) continue;
             total += n_reads;
@@ -625,7 +651,7 @@ int main(int argc, char** argv) {
     reader.join();
     writer.join();
     if (exit_code) return exit_code;
-    if (fclose(out) != 0) {
+    if (::close(out_fd) != 0) {
         logmsg("ERROR", "Error writing to result file");
         return 11;
     }
