@@ -1,6 +1,6 @@
 """Randomised parity soak: random small databases, reads of random lengths / damage, random parameters;
 the HIP path (both evaluation orders, through the C ABI) against the CPU oracle, every field of every hit
-and the work counters.  `python tools/fuzz_parity.py [iterations] [seed]`  (needs a GPU; ~1 s per iteration)."""
+and the work counters.  FUZZ_BIG=1 makes the batches large enough to run as concurrent lanes.  `python tools/fuzz_parity.py [iterations] [seed]`  (needs a GPU; ~1 s per iteration)."""
 import os
 import random
 import sys
@@ -47,7 +47,8 @@ def one(it, rng, tmp):
     max_len = rng.choice((40, 75, 100, 150, 151, 200, 250, 253, 300, 400))
     texts = [e[2] for e in entries]
     reads = []
-    for _ in range(rng.randrange(200, 1500)):
+    n_reads = rng.randrange(200, 1500) * (90 if os.environ.get("FUZZ_BIG") else 1)  # FUZZ_BIG: batches that run as lanes
+    for _ in range(n_reads):
         L = max_len if rng.random() < 0.3 else rng.randrange(1, max_len + 1)
         t = rng.choice(texts)
         if len(t) <= L or rng.random() < 0.1:
