@@ -25,7 +25,7 @@ namespace {
 // memcpy / first-touch split over a few threads for large host buffers
 template <class F>
 void parallel_ranges(uint64_t n, F f) {
-    const int nt = n >= (64ull << 20) ? 4 : n >= (8ull << 20) ? 2 : 1;
+    const int nt = n >= (32ull << 20) ? 4 : n >= (4ull << 20) ? 2 : 1;
     if (nt == 1) return f(0, n);
     std::vector<std::thread> th;
     const uint64_t chunk = ((n + nt - 1) / nt + 4095) & ~4095ull;
@@ -88,17 +88,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_out_off, ns + 1, &bytes);
     dev_alloc(&d_tile_sums, (uint64_t)scan_tiles((uint32_t)ns) + 1, &bytes);
     dev_alloc(&d_counters, kCounters, &bytes);
-    dev_alloc(&d_hit_row, hit_cap, &bytes);
-    dev_alloc(&d_hit_ref, hit_cap, &bytes);
-    dev_alloc(&d_hit_q, hit_cap, &bytes);
-    dev_alloc(&d_hit_key, hit_cap, &bytes);
-    dev_alloc(&d_cand_tmp, 2 * hit_cap, &bytes);
-    dev_alloc(&d_cand, hit_cap, &bytes);
-    dev_alloc(&d_out, hit_cap, &bytes);
-    dev_alloc(&d_cand_next, hit_cap, &bytes);
-    dev_alloc(&d_cand_rs, hit_cap, &bytes);
-    dev_alloc(&d_cand_status, hit_cap, &bytes);
-    dev_alloc(&d_worklist, hit_cap, &bytes);
+    alloc_hit_workspace();
     dev_alloc(&d_hits, hits_cap, &bytes);
     HIP_CHECK(hipHostMalloc((void**)&h_counters, kCounters * sizeof(uint64_t)));
     if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
@@ -121,19 +111,48 @@ Batch::~Batch() {
                     (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand, (void*)d_out,
                     (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_heavy_list})
         (void)hipFree(p);
-    (void)hipFree(d_bases2);
     (void)hipFree(d_codes);
-    if (h_hits_stage) (void)hipHostFree(h_hits_stage);
+    (void)hipFree(d_strip);
+    if (h_hits_stage) pinned_hits_release(h_hits_stage);
     if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
-    for (int b = 0; b < 2; b++) {
-        if (h_stage_bases[b]) (void)hipHostFree(h_stage_bases[b]);
-        if (h_stage_off[b]) (void)hipHostFree(h_stage_off[b]);
+    for (auto& rb : ring) {
+        (void)hipFree(rb.d_bases);
+        (void)hipFree(rb.d_off);
+        if (rb.h_bases) (void)hipHostFree(rb.h_bases);
+        if (rb.h_off) (void)hipHostFree(rb.h_off);
     }
-    (void)hipFree(d_read_off2);
-    if (copy_stream) (void)hipStreamDestroy(copy_stream);
+    for (auto& cs : copy_streams)
+        if (cs) (void)hipStreamDestroy(cs);
     (void)hipHostFree(h_counters);
     for (auto& e : ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(stream);
+}
+
+// the arrays indexed by seed hit / candidate; nothing of a pass lives in them before its locate stage
+void Batch::alloc_hit_workspace() {
+    dev_alloc(&d_hit_row, hit_cap, &bytes);
+    dev_alloc(&d_hit_ref, hit_cap, &bytes);
+    dev_alloc(&d_hit_q, hit_cap, &bytes);
+    dev_alloc(&d_hit_key, hit_cap, &bytes);
+    dev_alloc(&d_cand_tmp, 2 * hit_cap, &bytes);
+    dev_alloc(&d_cand, hit_cap, &bytes);
+    dev_alloc(&d_out, hit_cap, &bytes);
+    dev_alloc(&d_cand_next, hit_cap, &bytes);
+    dev_alloc(&d_cand_rs, hit_cap, &bytes);
+    dev_alloc(&d_cand_status, hit_cap, &bytes);
+    dev_alloc(&d_worklist, hit_cap, &bytes);
+}
+
+void Batch::grow_hit_workspace(uint64_t need) {
+    HIP_CHECK(hipStreamSynchronize(stream));
+    for (void* p : {(void*)d_hit_row, (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand,
+                    (void*)d_out, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_worklist})
+        (void)hipFree(p);
+    d_hit_row = d_hit_ref = d_hit_q = d_cand_next = d_cand_rs = d_cand_status = d_worklist = nullptr;
+    d_hit_key = d_cand_tmp = nullptr;
+    d_cand = d_out = nullptr;
+    hit_cap = need;
+    alloc_hit_workspace();
 }
 
 void Batch::upload(const uint8_t* bases, const uint64_t* read_off, uint64_t n) {
@@ -259,7 +278,7 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, con
             const uint64_t before = lane->n_hits_total;
             // base normalisation (binner.rs:88-100) of this chunk's bytes: raw -> codes, on the lane's stream
             if (raw) launch_normalise(lane->stream, raw, sb, h_off[a], h_off[b]);
-            lane->run_slice(p, sb, so + a, b - a, range_max_len, read_base + a);
+            lane->run_slice(p, sb, so + a, h_off ? h_off + a : nullptr, b - a, range_max_len, read_base + a);
             segs[c] = Segment{lane, before, lane->n_hits_total - before};
         }
     };
@@ -293,20 +312,43 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, con
 
 // One slice of reads already in HBM (bases `sb`, offsets `so`, `n_slice` reads whose first read is
 // number `read_base` of the caller's batch): passes over the slice, hits appended to d_hits.
-void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n_slice, uint32_t slice_max_len,
-                      uint64_t read_base) {
+// h_off: host copy of the slice's n_slice + 1 offsets (needed only when the slice holds reads beyond
+// kMaxRegisterReadLen bases).
+void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, const uint32_t* h_off, uint64_t n_slice,
+                      uint32_t slice_max_len, uint64_t read_base) {
     if (slice_max_len > kMaxReadLen)
         throw std::runtime_error("limit: read of " + std::to_string(slice_max_len) + " bases; this build verifies reads up to " +
                                  std::to_string(kMaxReadLen));
     const DevIndexView& v = di->view;
     const uint32_t K = p.seed_size, G = p.seed_interval;
-    const uint32_t max_ns = slice_max_len >= K ? (slice_max_len - K) / G + 1 : 0;
     float* stage_ms = stage_acc;
+    // Long reads (beyond the register-resident kernels) run in passes of their own, through the tiled kernel:
+    // a pass is a contiguous range of reads, so cutting the slice at them keeps the hits in read order, and
+    // the dense per-strand seed slots of the other passes stay sized for ordinary reads.
+    const bool mixed = slice_max_len > kMaxRegisterReadLen;
+    if (mixed && !h_off) throw std::runtime_error("internal: a slice with long reads needs its host offsets");
+    constexpr uint64_t kLongPassSlots = 16ull << 20;  // seed slots of one long-read pass, at most
 
     uint64_t pass_reads = n_slice;
     uint64_t r0 = 0;
     while (r0 < n_slice) {
-        const uint32_t nr = (uint32_t)std::min<uint64_t>(pass_reads, n_slice - r0);
+        uint32_t nr = (uint32_t)std::min<uint64_t>(pass_reads, n_slice - r0);
+        uint32_t pass_max_len = slice_max_len;
+        bool tiled = false;
+        if (mixed) {
+            auto len_of = [&](uint64_t i) { return h_off[i + 1] - h_off[i]; };
+            tiled = len_of(r0) > kMaxRegisterReadLen;
+            uint32_t cnt = 0, ml = 0;
+            while (cnt < nr && (len_of(r0 + cnt) > kMaxRegisterReadLen) == tiled) {
+                const uint32_t ml2 = std::max(ml, len_of(r0 + cnt));
+                if (tiled && cnt && 2ull * (cnt + 1) * (ml2 >= K ? (ml2 - K) / G + 1 : 0) > kLongPassSlots) break;
+                ml = ml2;
+                cnt++;
+            }
+            nr = cnt;
+            pass_max_len = ml;
+        }
+        const uint32_t max_ns = pass_max_len >= K ? (pass_max_len - K) / G + 1 : 0;
         const uint32_t nstr = nr * 2;
         const uint64_t slots = (uint64_t)nstr * max_ns;
         if (slots > seed_cap) {
@@ -337,11 +379,14 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         HIP_CHECK(hipStreamSynchronize(stream));
         const uint64_t total_hits = h_counters[0];
         if (total_hits > hit_cap) {
-            if (nr == 1)
-                throw std::runtime_error("device: one read has " + std::to_string(total_hits) +
-                                         " seed hits, more than the hit workspace (" + std::to_string(hit_cap) + ")");
-            pass_reads = std::max<uint64_t>(1, nr / 2);
-            continue;  // redo this pass with fewer reads
+            if (nr > 1) {
+                pass_reads = std::max<uint64_t>(1, nr / 2);
+                continue;  // redo this pass with fewer reads
+            }
+            // one read with more seed hits than the workspace (a long read in a repeat): grow the workspace
+            if (total_hits > 0xfffffff0ull)
+                throw std::runtime_error("device: one read has " + std::to_string(total_hits) + " seed hits, more than 2^32");
+            grow_hit_workspace(total_hits);
         }
         stats.n_passes++;
         stats.n_seed_slots += slots;
@@ -384,9 +429,27 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             a.wl_count = (const uint32_t*)(d_counters + 1);
             a.wl_cursor = (uint32_t*)(d_counters + 7);
             stats.n_rounds = 1;
-            if (verify_mode == 1 && slice_max_len <= 253) {
-                launch_edit_myers(stream, v, a, total_hits, slice_max_len);
-            } else if (sw_pairs && slice_max_len <= 253) {
+            if (tiled) {
+                // strips sized from the longest window of the pass (one small round trip; long reads are rare)
+                HIP_CHECK(hipMemsetAsync(d_counters + 13, 0, sizeof(uint64_t), stream));
+                launch_max_window(stream, nstr, d_strand_off, d_strand_ncand, d_cand, (unsigned long long*)(d_counters + 13));
+                HIP_CHECK(hipMemcpyAsync(h_counters + 13, d_counters + 13, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+                HIP_CHECK(hipStreamSynchronize(stream));
+                const uint32_t strip_len = (uint32_t)std::max<uint64_t>(h_counters[13], 1);
+                const uint64_t need = (uint64_t)tiled_groups(total_hits, strip_len) * strip_len;
+                if (need > strip_cap) {
+                    (void)hipFree(d_strip);
+                    d_strip = nullptr;
+                    uint64_t dummy = 0;
+                    dev_alloc(&d_strip, need, &dummy);
+                    strip_cap = need;
+                }
+                a.strip = d_strip;
+                a.strip_len = strip_len;
+                launch_evaluate_tiled(stream, v, a, total_hits);
+            } else if (verify_mode == 1 && pass_max_len <= 253) {
+                launch_edit_myers(stream, v, a, total_hits, pass_max_len);
+            } else if (sw_pairs && pass_max_len <= 253) {
                 // Reference order, split by predicate: k_sw_pairs runs the prefilter of index.rs:406 two
                 // candidates per group, k_edit_myers the edit distance of :407-410 on those that passed.
                 // A candidate that passes the first and fails the second sends its TaxId's next
@@ -402,20 +465,19 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     HIP_CHECK(hipMemsetAsync(d_counters + 8, 0, 3 * sizeof(uint64_t), stream));
                     HIP_CHECK(hipMemsetAsync(next_slot, 0, sizeof(uint64_t), stream));
                     EvalArgs sw = a;
-                    sw.flags = sw_diag ? 0u : 1u;
                     sw.worklist = wl;
                     sw.wl_count = wl_count;
                     sw.wl_cursor = (uint32_t*)(d_counters + 8);
                     sw.pass_list = pass_list;
                     sw.pass_count = (uint32_t*)(d_counters + 9);
-                    launch_sw_pairs(stream, v, sw, items, slice_max_len);
+                    launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag);
                     EvalArgs my = a;
                     my.worklist = pass_list;
                     my.wl_count = (const uint32_t*)(d_counters + 9);
                     my.wl_cursor = (uint32_t*)(d_counters + 10);
                     my.next_list = next_lists[round & 1];
                     my.next_count = (uint32_t*)next_slot;
-                    launch_edit_myers(stream, v, my, items, slice_max_len, true);
+                    launch_edit_myers(stream, v, my, items, pass_max_len, true);
                     HIP_CHECK(hipMemcpyAsync(h_counters + 11, next_slot, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipStreamSynchronize(stream));
                     const uint64_t n_next = h_counters[11] & 0xffffffffull;
@@ -426,7 +488,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     items = n_next;
                 }
             } else {
-                launch_evaluate(stream, v, a, total_hits, slice_max_len);
+                launch_evaluate(stream, v, a, total_hits, pass_max_len);
             }
             launch_resolve(stream, nstr, p.max_candidates, p.max_assignments, d_strand_off, d_strand_ncand, d_cand_status,
                            d_out, d_strand_nout);
@@ -445,6 +507,12 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             dev_alloc(&nh, ncap, &dummy);
             if (n_hits_total) HIP_CHECK(hipMemcpyAsync(nh, d_hits, n_hits_total * sizeof(DevHit), hipMemcpyDeviceToDevice, stream));
             HIP_CHECK(hipStreamSynchronize(stream));
+            // run_host may be copying an earlier slice's hits out of the old array on the owner's copy stream (and
+            // another lane's thread may be issuing such a copy right now: the commit mutex covers the pointer swap)
+            Batch* root = parent ? parent : this;
+            std::unique_lock<std::mutex> commit_lk;
+            if (root->commit_mu) commit_lk = std::unique_lock<std::mutex>(*root->commit_mu);
+            if (root->copy_stream2) HIP_CHECK(hipStreamSynchronize(root->copy_stream2));
             (void)hipFree(d_hits);
             d_hits = nh;
             hits_cap = ncap;
@@ -463,183 +531,303 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
     }
 }
 
-// Host buffers in, hits resident on the device out: the batch is cut into slices of at most
-// max_reads reads / max_bases bases; an uploader thread copies slice k+1 into the second input
-// buffer on its own stream while the kernels of slice k run, so PCIe time hides behind compute
-// (pageable host memory makes hipMemcpyAsync block its caller, hence the thread).
+// ---------------------------------------------------------------------------------------------
+// Pinned result arrays.  The hits of a run travel to page-locked host memory slice by slice while later
+// slices still compute, and that array itself is what the caller receives (mtsv_hits_free hands it back
+// to this pool), so no copy into fresh malloc memory -- page faults at ~12 GB/s -- sits behind the kernels.
+// ---------------------------------------------------------------------------------------------
+namespace {
+struct PinnedPool {
+    std::mutex mu;
+    std::vector<std::pair<void*, uint64_t>> free_list;  // (pointer, bytes)
+    std::vector<std::pair<void*, uint64_t>> live;
+    static constexpr size_t kKeep = 6;  // idle arrays kept for reuse
+    void* get(uint64_t bytes, uint64_t* cap) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t best = free_list.size();
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].second >= bytes && (best == free_list.size() || free_list[i].second < free_list[best].second)) best = i;
+            if (best != free_list.size()) {
+                auto e = free_list[best];
+                free_list.erase(free_list.begin() + best);
+                live.push_back(e);
+                *cap = e.second;
+                return e.first;
+            }
+        }
+        void* p = nullptr;
+        const uint64_t b = std::max<uint64_t>((bytes + (bytes >> 3) + 4095) & ~4095ull, 1ull << 16);
+        HIP_CHECK(hipHostMalloc(&p, b, hipHostMallocPortable));
+        std::lock_guard<std::mutex> lk(mu);
+        live.emplace_back(p, b);
+        *cap = b;
+        return p;
+    }
+    bool put(void* p) {  // false: not one of ours
+        std::pair<void*, uint64_t> drop{nullptr, 0};
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            size_t i = 0;
+            while (i < live.size() && live[i].first != p) i++;
+            if (i == live.size()) return false;
+            auto e = live[i];
+            live.erase(live.begin() + i);
+            free_list.push_back(e);
+            if (free_list.size() > kKeep) {  // drop the smallest
+                size_t m = 0;
+                for (size_t k = 1; k < free_list.size(); k++)
+                    if (free_list[k].second < free_list[m].second) m = k;
+                drop = free_list[m];
+                free_list.erase(free_list.begin() + m);
+            }
+        }
+        if (drop.first) (void)hipHostFree(drop.first);
+        return true;
+    }
+};
+PinnedPool& pool() {
+    static PinnedPool* p = new PinnedPool;  // never destroyed: arrays may outlive static destruction order
+    return *p;
+}
+}  // namespace
+
+mtsv_hit* pinned_hits_alloc(uint64_t n_hits, uint64_t* cap_hits) {
+    uint64_t cap = 0;
+    void* p = pool().get(std::max<uint64_t>(n_hits, 1) * sizeof(mtsv_hit), &cap);
+    *cap_hits = cap / sizeof(mtsv_hit);
+    return (mtsv_hit*)p;
+}
+bool pinned_hits_release(void* p) { return p && pool().put(p); }
+
+// Host buffers in, hits in pinned host memory out.  The reads are cut into slices of at most one lane's
+// workspace; `uploaders` threads stage slice k through pinned memory into ring buffer k % NB (host memcpy,
+// DMA on the thread's copy stream, base normalisation there too) while the lanes -- one host thread and
+// stream each -- pull ready slices in order and run the pipeline on them.  A finished slice's hits start
+// their way to the pinned result array at once, in slice order, on a third stream.  Nothing waits for a
+// whole batch: the steady state runs at max(kernels, staging, DMA).
 void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p) {
     HIP_CHECK(hipSetDevice(di->device));
-    if (!d_bases2) {
-        dev_alloc(&d_bases2, max_bases + 64, &bytes);
-        dev_alloc(&d_read_off2, max_reads + 1, &bytes);
-        HIP_CHECK(hipStreamCreateWithFlags(&copy_stream, hipStreamNonBlocking));
-        // pinned staging: a copy from pageable memory runs at ~5-20 GB/s on this platform, from pinned
-        // memory at ~57 GB/s (tools/pcie_rates.hip), and a host memcpy into it at >20 GB/s per thread
-        for (int b = 0; b < 2; b++) {
-            HIP_CHECK(hipHostMalloc((void**)&h_stage_bases[b], max_bases + 64));
-            HIP_CHECK(hipHostMalloc((void**)&h_stage_off[b], (max_reads + 1) * sizeof(uint32_t)));
+    std::vector<Batch*> ls{this};
+    for (auto& l : extra) ls.push_back(l.get());
+    const size_t NB = ls.size() + 2;
+    const uint64_t slice_reads = ws_reads;
+    const uint64_t slice_bases = std::max<uint64_t>(max_bases / ls.size() + 4096, 1 << 16);
+    if (ring.size() != NB) {
+        ring.resize(NB);
+        for (auto& rb : ring) {
+            dev_alloc(&rb.d_bases, slice_bases + 64, &bytes);
+            dev_alloc(&rb.d_off, slice_reads + 1, &bytes);
+            HIP_CHECK(hipHostMalloc((void**)&rb.h_bases, slice_bases + 64));
+            HIP_CHECK(hipHostMalloc((void**)&rb.h_off, (slice_reads + 1) * sizeof(uint32_t)));
         }
+        for (auto& cs : copy_streams) HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
+        HIP_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
     }
     const bool trace = getenv("MTSV_TRACE") != nullptr;
     struct Slice {
-        uint64_t begin, end;
-        uint32_t max_len;
+        uint64_t begin = 0, end = 0;
+        uint32_t max_len = 0;
+        bool ready = false, done = false;
+        Batch* lane = nullptr;
+        uint64_t hit_off = 0, hit_cnt = 0;
     };
-    std::mutex mu;
+    std::mutex mu;  // slices, cursors, commit state
     std::condition_variable cv;
-    std::vector<Slice> ready;
-    uint64_t consumed = 0;
-    bool upload_done = false, abort = false;
-    std::exception_ptr upload_err;
-    uint8_t* const buf_b[2] = {d_bases, d_bases2};
-    uint32_t* const buf_o[2] = {d_read_off, d_read_off2};
+    std::vector<Slice> slices;
+    uint64_t cut_at = 0;       // reads already cut into slices
+    uint64_t released = 0;     // slices [0, released) have left their ring buffers
+    uint64_t next_take = 0;    // next slice a lane takes
+    uint64_t next_commit = 0;  // next slice whose hits go to the host
+    bool abort = false;
+    std::exception_ptr first_err;
+    auto fail = [&](std::exception_ptr e) {
+        std::lock_guard<std::mutex> lk(mu);
+        if (!first_err) first_err = e;
+        abort = true;
+        cv.notify_all();
+    };
 
-    std::thread uploader([&] {
+    n_reads = n;
+    max_len = 0;
+    begin_run(p);
+    staged_hits = 0;
+    if (!h_hits_stage) {
+        // expect about as many hits as the last run produced (first run: one per read)
+        h_hits_stage = pinned_hits_alloc(std::max<uint64_t>(last_total_hits + last_total_hits / 8, std::min<uint64_t>(n, 1ull << 22)), &h_hits_cap);
+    }
+
+    // ---- uploaders ----
+    auto uploader = [&](int tid) {
         try {
             HIP_CHECK(hipSetDevice(di->device));
-            uint64_t s = 0, k = 0;
-            while (s < n) {
+            hipStream_t cs = copy_streams[tid];
+            for (;;) {
+                uint64_t k, s, e;
                 {
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return abort || k < consumed + 2; });
-                    if (abort) break;
-                }
-                uint64_t e = std::min(n, s + max_reads);
-                if (read_off[e] < read_off[s]) throw std::runtime_error("arg: read_off is not ascending");
-                if (read_off[e] - read_off[s] > max_bases) {  // largest e with at most max_bases bases
-                    uint64_t lo = s, hi = e;
-                    while (lo < hi) {
-                        uint64_t mid = (lo + hi + 1) / 2;
-                        if (read_off[mid] >= read_off[s] && read_off[mid] - read_off[s] <= max_bases) lo = mid;
-                        else hi = mid - 1;
+                    if (abort || cut_at >= n) return;
+                    // cut the next slice: a short first one so the kernels start early, then full ones
+                    s = cut_at;
+                    k = slices.size();
+                    uint64_t want = slice_reads;
+                    if (k < 3 && n > 2 * slice_reads) want = std::max<uint64_t>(slice_reads >> (3 - k), 4096);
+                    e = std::min(n, s + want);
+                    if (read_off[e] < read_off[s]) throw std::runtime_error("arg: read_off is not ascending");
+                    if (read_off[e] - read_off[s] > slice_bases) {  // largest e with at most slice_bases bases
+                        uint64_t lo = s, hi = e;
+                        while (lo < hi) {
+                            uint64_t mid = (lo + hi + 1) / 2;
+                            if (read_off[mid] >= read_off[s] && read_off[mid] - read_off[s] <= slice_bases) lo = mid;
+                            else hi = mid - 1;
+                        }
+                        e = lo;
+                        if (e == s) throw std::runtime_error("limit: one read holds more bases than the batch workspace");
                     }
-                    e = lo;
-                    if (e == s) throw std::runtime_error("limit: one read holds more bases than the batch workspace");
+                    slices.emplace_back();
+                    slices[k].begin = s;
+                    slices[k].end = e;
+                    cut_at = e;
+                    cv.wait(lk, [&] { return abort || k < released + NB; });  // ring buffer k % NB is free
+                    if (abort) return;
                 }
+                RingBuf& rb = ring[k % NB];
                 const uint64_t cnt = e - s, first = read_off[s], nb = read_off[e] - first;
-                uint32_t* off32 = h_stage_off[k & 1];
                 uint32_t ml = 0;
                 for (uint64_t i = 0; i <= cnt; i++) {
                     if (i && read_off[s + i] < read_off[s + i - 1]) throw std::runtime_error("arg: read_off is not ascending");
-                    off32[i] = (uint32_t)(read_off[s + i] - first);
-                    if (i) ml = std::max(ml, off32[i] - off32[i - 1]);
+                    rb.h_off[i] = (uint32_t)(read_off[s + i] - first);
+                    if (i) ml = std::max(ml, rb.h_off[i] - rb.h_off[i - 1]);
                 }
                 const double t0 = now_s();
                 if (nb) {
-                    parallel_copy(h_stage_bases[k & 1], bases + first, nb);
-                    HIP_CHECK(hipMemcpyAsync(buf_b[k & 1], h_stage_bases[k & 1], nb, hipMemcpyHostToDevice, copy_stream));
+                    parallel_copy(rb.h_bases, bases + first, nb);
+                    HIP_CHECK(hipMemcpyAsync(rb.d_bases, rb.h_bases, nb, hipMemcpyHostToDevice, cs));
                 }
-                launch_normalise(copy_stream, buf_b[k & 1], buf_b[k & 1], 0, nb);  // in place: a slice is consumed once
-                HIP_CHECK(hipMemcpyAsync(buf_o[k & 1], off32, (cnt + 1) * 4, hipMemcpyHostToDevice, copy_stream));
+                launch_normalise(cs, rb.d_bases, rb.d_bases, 0, nb);  // in place: a slice is consumed once
+                HIP_CHECK(hipMemcpyAsync(rb.d_off, rb.h_off, (cnt + 1) * 4, hipMemcpyHostToDevice, cs));
                 const double t1 = now_s();
-                HIP_CHECK(hipStreamSynchronize(copy_stream));
-                if (trace) fprintf(stderr, "[run_host] slice %llu: stage %.1f ms, h2d %.1f ms (%.1f MB)\n", (unsigned long long)k, (t1 - t0) * 1e3, (now_s() - t1) * 1e3, nb / 1e6);
+                HIP_CHECK(hipStreamSynchronize(cs));
+                if (trace) fprintf(stderr, "[run_host] slice %llu (%llu reads): stage %.1f ms, h2d %.1f ms (%.1f MB) at %.1f ms\n", (unsigned long long)k, (unsigned long long)cnt, (t1 - t0) * 1e3, (now_s() - t1) * 1e3, nb / 1e6, (now_s() - run_t0) * 1e3);
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    ready.push_back(Slice{s, e, ml});
+                    slices[k].max_len = ml;
+                    slices[k].ready = true;
                 }
                 cv.notify_all();
-                s = e;
-                k++;
             }
         } catch (...) {
-            std::lock_guard<std::mutex> lk(mu);
-            upload_err = std::current_exception();
+            fail(std::current_exception());
         }
-        {
-            std::lock_guard<std::mutex> lk(mu);
-            upload_done = true;
-        }
-        cv.notify_all();
-    });
+    };
 
-    std::exception_ptr err;
-    try {
-        n_reads = n;
-        max_len = 0;
-        begin_run(p);
-        if (!copy_stream2) HIP_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
-        staged_hits = 0;
-        for (uint64_t k = 0;; k++) {
-            Slice sl;
-            {
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return ready.size() > k || upload_done; });
-                if (upload_err) std::rethrow_exception(upload_err);
-                if (ready.size() <= k) break;
-                sl = ready[k];
-            }
-            max_len = std::max(max_len, sl.max_len);
-            const double t0 = now_s();
-            const size_t seg0 = segments.size();
-            run_range(p, nullptr, buf_b[k & 1], buf_o[k & 1], nullptr, sl.end - sl.begin, sl.max_len, sl.begin);
-            if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3);
-            // this slice's hits start their way to the host (pinned staging) under the next slice's kernels
-            for (size_t si = seg0; si < segments.size(); si++) {
-                const Segment& sg = segments[si];
-                if (!sg.count) continue;
-                stage_reserve(staged_hits + sg.count);
-                HIP_CHECK(hipMemcpyAsync(h_hits_stage + staged_hits, sg.lane->d_hits + sg.offset, sg.count * sizeof(mtsv_hit),
+    // ---- lanes ----
+    auto commit_ready = [&]() {  // mu held: hits of finished slices leave for the host in slice order
+        while (next_commit < slices.size() && slices[next_commit].done) {
+            Slice& sl = slices[next_commit];
+            if (sl.hit_cnt) {
+                stage_reserve(staged_hits + sl.hit_cnt);
+                HIP_CHECK(hipMemcpyAsync(h_hits_stage + staged_hits, sl.lane->d_hits + sl.hit_off, sl.hit_cnt * sizeof(mtsv_hit),
                                          hipMemcpyDeviceToHost, copy_stream2));
-                staged_hits += sg.count;
+                staged_hits += sl.hit_cnt;
             }
-            {
-                std::lock_guard<std::mutex> lk(mu);
-                consumed = k + 1;
-            }
-            cv.notify_all();
+            segments.push_back(Segment{sl.lane, sl.hit_off, sl.hit_cnt});
+            next_commit++;
         }
-        end_run();
-        HIP_CHECK(hipStreamSynchronize(copy_stream2));
-        staged_valid = staged_hits == total_hits;
-    } catch (...) {
-        err = std::current_exception();
+    };
+    auto lane_main = [&](Batch* lane) {
+        try {
+            HIP_CHECK(hipSetDevice(di->device));
+            for (;;) {
+                uint64_t k;
+                Slice sl;
+                {
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] {
+                        return abort || (next_take < slices.size() && slices[next_take].ready) || (cut_at >= n && next_take >= slices.size());
+                    });
+                    if (abort || next_take >= slices.size()) return;  // failed elsewhere / every slice taken
+                    k = next_take++;
+                    sl = slices[k];
+                }
+                cv.notify_all();
+                const RingBuf& rb = ring[k % NB];
+                const uint64_t before = lane->n_hits_total;
+                const double t0 = now_s();
+                lane->run_slice(p, rb.d_bases, rb.d_off, rb.h_off, sl.end - sl.begin, sl.max_len, sl.begin);
+                if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms, done at %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3, (now_s() - run_t0) * 1e3);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    slices[k].lane = lane;
+                    slices[k].hit_off = before;
+                    slices[k].hit_cnt = lane->n_hits_total - before;
+                    slices[k].done = true;
+                    max_len = std::max(max_len, sl.max_len);
+                    // ring buffers leave in order: slice k's buffer is reusable once every earlier one is
+                    while (released < slices.size() && slices[released].done) released++;
+                    commit_ready();
+                }
+                cv.notify_all();
+            }
+        } catch (...) {
+            fail(std::current_exception());
+        }
+    };
+
+    commit_mu = &mu;
+    std::vector<std::thread> th;
+    const uint64_t n_lanes_used = n >= ls.size() * kLaneMinReads ? ls.size() : 1;
+    lanes_used = n_lanes_used;
+    for (int t = 0; t < kUploaders; t++) th.emplace_back(uploader, t);
+    for (uint64_t i = 1; i < n_lanes_used; i++) th.emplace_back(lane_main, ls[i]);
+    lane_main(this);
+    for (auto& t : th) t.join();
+    commit_mu = nullptr;
+    if (first_err) {
+        (void)hipStreamSynchronize(copy_stream2);
+        std::rethrow_exception(first_err);
     }
-    {
-        std::lock_guard<std::mutex> lk(mu);
-        abort = true;
-    }
-    cv.notify_all();
-    uploader.join();
-    if (err) std::rethrow_exception(err);
+    end_run();
+    HIP_CHECK(hipStreamSynchronize(copy_stream2));
+    staged_valid = staged_hits == total_hits;
+    if (!staged_valid) throw std::runtime_error("internal: run_host staged " + std::to_string(staged_hits) + " of " + std::to_string(total_hits) + " hits");
 }
 
-// pinned staging of run_host's hits: grown geometrically, kept for the life of the workspace
+// pinned result array of run_host: grown geometrically through the pool (mu of run_host held)
 void Batch::stage_reserve(uint64_t n_hits_needed) {
     if (n_hits_needed <= h_hits_cap) return;
     HIP_CHECK(hipStreamSynchronize(copy_stream2));
-    const uint64_t ncap = std::max<uint64_t>(std::max<uint64_t>(2 * h_hits_cap, n_hits_needed), 1ull << 20);
-    mtsv_hit* nh = nullptr;
-    HIP_CHECK(hipHostMalloc((void**)&nh, ncap * sizeof(mtsv_hit)));
+    uint64_t ncap = 0;
+    mtsv_hit* nh = pinned_hits_alloc(std::max<uint64_t>(2 * h_hits_cap, n_hits_needed), &ncap);
     if (staged_hits) memcpy(nh, h_hits_stage, staged_hits * sizeof(mtsv_hit));
-    if (h_hits_stage) (void)hipHostFree(h_hits_stage);
+    if (h_hits_stage) pinned_hits_release(h_hits_stage);
     h_hits_stage = nh;
     h_hits_cap = ncap;
 }
 
+// The result array is pinned host memory from the pool; the caller owns it until mtsv_hits_free.
 void Batch::download(mtsv_hit** hits, uint64_t* n) {
     HIP_CHECK(hipSetDevice(di->device));
-    mtsv_hit* h = (mtsv_hit*)malloc(std::max<uint64_t>(total_hits, 1) * sizeof(mtsv_hit));
-    if (!h) throw std::runtime_error("nomem: result array");
-    if (total_hits && staged_valid) {  // run_host already brought them over: one parallel host copy
-        parallel_copy((uint8_t*)h, (const uint8_t*)h_hits_stage, total_hits * sizeof(mtsv_hit));
-    } else if (total_hits) {
-        // fault the fresh pages in from several threads: a D2H copy into untouched malloc memory is
-        // page-fault bound (~12 GB/s instead of ~55)
-        uint8_t* hb = (uint8_t*)h;
-        parallel_ranges(total_hits * sizeof(mtsv_hit), [=](uint64_t a, uint64_t b) {
-            for (uint64_t o = a; o < b; o += 4096) hb[o] = 0;
-        });
-        uint64_t at = 0;
-        for (auto& sg : segments) {
-            if (!sg.count) continue;
-            hipError_t e = hipMemcpy(h + at, sg.lane->d_hits + sg.offset, sg.count * sizeof(mtsv_hit), hipMemcpyDeviceToHost);
-            if (e != hipSuccess) {
-                free(h);
-                throw_hip(e, "hipMemcpy(hits)", __FILE__, __LINE__);
-            }
-            at += sg.count;
+    last_total_hits = total_hits;
+    if (staged_valid) {  // run_host already brought them over
+        *hits = h_hits_stage;
+        *n = total_hits;
+        h_hits_stage = nullptr;
+        h_hits_cap = 0;
+        staged_valid = false;
+        return;
+    }
+    uint64_t cap = 0;
+    mtsv_hit* h = pinned_hits_alloc(total_hits, &cap);
+    uint64_t at = 0;
+    for (auto& sg : segments) {
+        if (!sg.count) continue;
+        hipError_t e = hipMemcpy(h + at, sg.lane->d_hits + sg.offset, sg.count * sizeof(mtsv_hit), hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            pinned_hits_release(h);
+            throw_hip(e, "hipMemcpy(hits)", __FILE__, __LINE__);
         }
+        at += sg.count;
     }
     *hits = h;
     *n = total_hits;

@@ -1,6 +1,7 @@
 // batch.hpp -- device workspace of one read batch (see batch.hip).
 #pragma once
 #include <memory>
+#include <mutex>
 #include <vector>
 
 #include "../../include/mtsv_amd.h"
@@ -12,10 +13,21 @@ namespace mtsv {
 struct Batch {
     mtsv_index* ix;
     DeviceIndex* di;
-    hipStream_t stream = nullptr, copy_stream = nullptr, copy_stream2 = nullptr;
-    mtsv_hit* h_hits_stage = nullptr;  // pinned: run_host copies every slice's hits here while the next slice runs
-    uint64_t h_hits_cap = 0, staged_hits = 0;
+    hipStream_t stream = nullptr, copy_stream2 = nullptr;
+    mtsv_hit* h_hits_stage = nullptr;  // pinned (pool): run_host copies every slice's hits here while later slices run
+    uint64_t h_hits_cap = 0, staged_hits = 0, last_total_hits = 0;
     bool staged_valid = false;
+    // run_host: ring of input slices (device buffer + pinned staging each), filled by kUploaders threads
+    struct RingBuf {
+        uint8_t* d_bases = nullptr;
+        uint32_t* d_off = nullptr;
+        uint8_t* h_bases = nullptr;
+        uint32_t* h_off = nullptr;
+    };
+    static constexpr int kUploaders = 2;
+    std::vector<RingBuf> ring;
+    hipStream_t copy_streams[kUploaders] = {nullptr, nullptr};
+    std::mutex* commit_mu = nullptr;  // set while run_host's threads may touch the lanes' result arrays
     uint64_t max_reads, max_bases, hit_cap, hits_cap = 0;
     uint64_t bytes = 0;
     // Lanes: the workspace is cut into n_lanes equal parts, each with its own stream; a resident range of
@@ -36,8 +48,8 @@ struct Batch {
     uint64_t lanes_used = 1;
 
     uint8_t* d_codes = nullptr;  // run(): normalised copy of d_bases
-    uint8_t *d_bases = nullptr, *d_bases2 = nullptr;  // second input buffer: run_host() double-buffers slices
-    uint32_t *d_read_off = nullptr, *d_read_off2 = nullptr;
+    uint8_t* d_bases = nullptr;  // resident batch of upload() / run()
+    uint32_t* d_read_off = nullptr;
     uint32_t *d_seed_lo = nullptr, *d_seed_cnt = nullptr, *d_seed_pre = nullptr;
     uint64_t seed_cap = 0;
     uint32_t *d_strand_hits = nullptr, *d_strand_nseeds = nullptr, *d_strand_off = nullptr, *d_strand_ncand = nullptr,
@@ -49,9 +61,9 @@ struct Batch {
     uint4 *d_cand = nullptr, *d_out = nullptr;
     uint32_t *d_cand_next = nullptr, *d_cand_rs = nullptr, *d_cand_status = nullptr, *d_heavy_list = nullptr;
     DevHit* d_hits = nullptr;
+    uint2* d_strip = nullptr;  // tiled long-read kernel: band hand-over strips, allocated when a pass first needs them
+    uint64_t strip_cap = 0;
     uint64_t* h_counters = nullptr;  // pinned
-    uint8_t* h_stage_bases[2] = {nullptr, nullptr};  // pinned staging of run_host()
-    uint32_t* h_stage_off[2] = {nullptr, nullptr};
     hipEvent_t ev[10];
 
     std::vector<uint32_t> h_read_off;
@@ -80,12 +92,18 @@ struct Batch {
     void reset_lane();
     void stage_reserve(uint64_t n_hits_needed);
     void finish_lane();
+    void alloc_hit_workspace();
+    void grow_hit_workspace(uint64_t need);
     void run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, const uint32_t* so, const uint32_t* h_off, uint64_t n,
                    uint32_t range_max_len, uint64_t read_base);
-    void run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, uint64_t n_slice, uint32_t slice_max_len,
-                   uint64_t read_base);
+    void run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* so, const uint32_t* h_off, uint64_t n_slice,
+                   uint32_t slice_max_len, uint64_t read_base);
     void end_run();
 };
+
+// result arrays in pinned host memory, recycled through a pool (mtsv_hits_free returns them)
+mtsv_hit* pinned_hits_alloc(uint64_t n_hits, uint64_t* cap_hits);
+bool pinned_hits_release(void* p);  // false: p is not a pool array
 
 }  // namespace mtsv
 

@@ -249,7 +249,9 @@ int mtsv_bin_batch(mtsv_index* ix, int hip_device, const uint8_t* bases, const u
     })
 }
 
-void mtsv_hits_free(mtsv_hit* hits) { free(hits); }
+void mtsv_hits_free(mtsv_hit* hits) {
+    if (hits && !mtsv::pinned_hits_release(hits)) free(hits);
+}
 void mtsv_free(void* p) { free(p); }
 
 // ---- write_assignments (src/binner.rs:310-379) ------------------------------------------------

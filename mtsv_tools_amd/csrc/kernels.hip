@@ -17,6 +17,8 @@
 //
 // All arithmetic is integer; positions are u32 (n < 2^32).  No MFMA: the path is rank queries and
 // small dynamic programs.
+#include <stdexcept>
+
 #include "kernels.hpp"
 
 namespace mtsv {
@@ -998,16 +1000,26 @@ enum : uint32_t { PH_FETCH = 0, PH_SWEEP = 1, PH_DONE = 2, PH_CHAIN = 3, PH_WAIT
 // gap crosses a stripe boundary (read rows that are multiples of segLen = ceil(L/8)) by one cell only
 // and E never sees the lazy correction.  Row-wise that is: hb = max(0, diag+s, left_pre-1);
 // h = max(hb, up_pre-1); pre = boundary row ? hb : h -- computed here next to the exact score.
-template <int R, bool WORD, int GS>
+// TILED: reads of any length (up to 32767 bases, the range of the packed 16-bit cells).  The GS*R rows the
+// group's registers hold are one band of the matrix; the bands are swept top to bottom, each over all
+// columns of the window, and the bottom row of a band (both recurrences and the word-kernel pair) travels
+// to the next band through a per-group strip in HBM: lane GS-1 writes column j after computing it, lane 0
+// of the next band reads it as its row above (it runs GS-1 columns ahead of the writer, so one strip
+// serves both directions).  Padding rows sit above the first band.
+template <int R, bool WORD, int GS, bool TILED = false>
 __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)) void k_evaluate(DevIndexView ix, EvalArgs a) {
+    static_assert(!TILED || WORD, "the tiled kernel is the long-read path: it carries the word kernel");
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][kRing];
     const uint32_t lane = lane_id();
     const uint32_t gl = lane & (GS - 1);  // lane inside the group
     uint8_t* ring = ring_all[threadIdx.x / GS];
+    uint2* strip = TILED ? a.strip + (uint64_t)(blockIdx.x * (256 / GS) + threadIdx.x / GS) * a.strip_len : nullptr;
+    uint32_t band = 0, n_bands = 1;  // TILED: current band and bands of the strand's read
+    uint2 bnd_next = make_uint2(0, 0);
+    uint32_t b0_read = 0, strand_read = 0;
     const uint32_t n_work = *a.wl_count;
     const pk16 one = pk(1, 1), miss = pk(-1, -1);
-    const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
-                                               : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
+    const uint32_t maxc = a.maxc;  // max_candidates as a rank bound, clamped on the host
 
     uint32_t phase = PH_FETCH;
     uint32_t loc = 0, loc_end = 0;  // this group's slice of the worklist, refilled 4 items at a time
@@ -1052,6 +1064,17 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
                     thr_wrapped = 2ull * ED > (uint64_t)L;         // usize wrap of index.rs:406: nothing can pass
                     thr = L - 2 * ED;
                     const uint8_t* read = a.bases + b0;
+                    if (TILED) {
+                        n_bands = (L + GS * R - 1) / (GS * R);
+                        b0_read = b0;
+                        strand_read = strand;
+                        // an N of the read never matches in the edit-distance recurrence: edits >= #N
+                        int nn = 0;
+                        for (uint32_t p = gl; p < L; p += GS) nn += strand_code(read, L, strand, p) == kCodeN;
+#pragma unroll
+                        for (int d = 1; d < GS; d <<= 1) nn += __shfl_xor(nn, d);
+                        hopeless = thr_wrapped || (uint32_t)nn > ED;
+                    } else {
                     const int pad = (int)(GS * R) - (int)L;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
@@ -1076,6 +1099,7 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
 #pragma unroll
                     for (int d = 1; d < GS; d <<= 1) nn += __shfl_xor(nn, d);
                     hopeless = thr_wrapped || (uint32_t)nn > ED;
+                    }
                 } else {
                     phase = PH_DONE;
                     have = false;
@@ -1098,25 +1122,6 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
             if (have) {  // (re)start a sweep: candidate g of the strand whose rows are already loaded
                 const uint4 c = a.cand[g];
                 const DevBin bin = ix.bins[c.z];
-                const int pad = (int)(GS * R) - (int)L;
-#pragma unroll
-                for (int r = 0; r < R; r++) {
-                    int p = (int)(gl * R + r) - pad;
-                    h[r] = pk(0, p >= 0 ? -(p + 1) : 0);  // column 0: H = 0, D[i][0] = i
-                }
-                {
-                    int p0 = (int)(gl * R) - pad;  // row above this lane's first row, at column 0
-                    up_prev = pk(0, p0 > 0 ? -p0 : 0);
-                }
-                if (WORD) {
-                    upw_prev = 0;
-                    bestw = 0;
-#pragma unroll
-                    for (int r = 0; r < (WORD ? R : 1); r++) {
-                        hw[r] = 0;
-                        hwp[r] = 0;
-                    }
-                }
                 wstart = c.x;
                 Wn = c.y - c.x;
                 c_tax = bin.tax_id;
@@ -1124,20 +1129,59 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
                 c_off = c.x >= bin.start ? c.x - bin.start : 0;  // index.rs:416
                 verified++;
                 wbytes += Wn;
+                band = 0;
+                best = pk(0, -32768);
+                if (WORD) bestw = 0;
+                phase = PH_SWEEP;
+                t = steps = 0;  // the band set-up below starts the sweep
+            }
+        }
+        if (__all(phase == PH_DONE)) break;
+        if (phase == PH_SWEEP && t >= steps) {  // set up band `band` of candidate g (the only band unless TILED)
+            {
+                const int pad = (int)(n_bands * GS * R) - (int)L;
+                const int row0 = (int)(band * GS * R + gl * R) - pad;  // read position of this lane's first row
+                if (TILED) {  // this band's rows of the read
+                    const uint8_t* read = a.bases + b0_read;
+                    const int seg8 = (int)((L + 7) / 8);  // qP_word, ssw.c:336
+                    bmask = 0;
+#pragma unroll
+                    for (int r = 0; r < R; r++) {
+                        const int p = row0 + r;
+                        qc[r] = p >= 0 ? strand_code(read, L, strand_read, (uint32_t)p) : 6u;
+                        clampRow[r] = p >= 0 ? pk(0, -32768) : pk(0, 0);
+                        if (p >= 0 && p % seg8 == 0) bmask |= 1u << r;
+                    }
+                }
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    int p = row0 + r;
+                    h[r] = pk(0, p >= 0 ? -(p + 1) : 0);  // column 0: H = 0, D[i][0] = i
+                }
+                up_prev = pk(0, row0 > 0 ? -row0 : 0);  // row above this lane's first row, at column 0
+                if (WORD) {
+                    upw_prev = 0;
+#pragma unroll
+                    for (int r = 0; r < (WORD ? R : 1); r++) {
+                        hw[r] = 0;
+                        hwp[r] = 0;
+                    }
+                }
+                if (TILED && band > 0) {
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // the strip lane GS-1 wrote during the band above
+                    if (gl == 0) bnd_next = strip[0];
+                }
                 const uint32_t lim = min(Wn, kRing);
                 for (uint32_t base = 0; base < lim; base += 16 * GS) {  // 16 symbols per lane per pass
                     const uint32_t col = base + gl * 16;
                     if (col < lim) *reinterpret_cast<uint4*>(ring + col) = load16(ix.text, ix.n, wstart + col);
                 }
-                best = pk(0, -32768);
-                last = h[R - 1];  // min over the last row starts at D[L][0] (only lane 15 is read)
+                last = h[R - 1];  // min over the last row starts at D[L][0] (only lane 15 of the last band is read)
                 t = 0;
                 steps = Wn + GS - 1;
                 c_next = ring[(0u - gl) & (kRing - 1)];
-                phase = PH_SWEEP;
             }
         }
-        if (__all(phase == PH_DONE)) break;
         if (phase == PH_SWEEP) {
             // windows longer than the ring: once every lane has crossed a half boundary b (lane 15 lags
             // by 15 columns), overwrite columns [b-512, b) with [b+512, b+1024)
@@ -1201,10 +1245,15 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
             c_next = ring[(uint32_t)(j + 1) & (kRing - 1)];
             int in_bits = row_shr1(pk_bits(h[R - 1]));
             if (GS < 16 && gl == 0) in_bits = 0;  // a DPP row holds two groups: cut the shift at the group edge
-            const pk16 in = pk_from_bits(in_bits);  // lane 0 of the group reads 0: H = 0, D[0][j] = 0
             int inw = 0;
             if (WORD) inw = row_shr1((hw[(WORD ? R : 1) - 1] << 16) | hwp[(WORD ? R : 1) - 1]);  // (post, pre) of the row above
             if (WORD && GS < 16 && gl == 0) inw = 0;
+            if (TILED && band > 0 && gl == 0 && j >= 0 && j < (int)Wn) {  // bottom row of the band above, column j
+                in_bits = (int)bnd_next.x;
+                inw = (int)bnd_next.y;
+                if (j + 1 < (int)Wn) bnd_next = strip[j + 1];
+            }
+            const pk16 in = pk_from_bits(in_bits);  // lane 0 of the first band reads 0: H = 0, D[0][j] = 0
             if (j >= 0 && j < (int)Wn) {
                 const pk16 mvc = c == kCodeN ? pk(1, -1) : pk(1, 0);  // N/N: +1 in SW, never a match in edit distance
                 pk16 diag = up_prev, up = in;
@@ -1240,11 +1289,15 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
                     }
                     upw_prev = inw >> 16;
                 }
+                if (TILED && gl == GS - 1 && band + 1 < n_bands)
+                    strip[j] = make_uint2((uint32_t)pk_bits(h[R - 1]), ((uint32_t)hw[(WORD ? R : 1) - 1] << 16) | (uint32_t)hwp[(WORD ? R : 1) - 1]);
             }
             t++;
             if (t >= steps) break;
           }
-            if (t >= steps) {
+            if (TILED && t >= steps && band + 1 < n_bands) {
+                band++;  // next band of the same candidate: set up at the top of the loop (t >= steps still holds)
+            } else if (t >= steps) {
                 int sw = best.x;
 #pragma unroll
                 for (int d = 1; d < GS; d <<= 1) sw = max(sw, __shfl_xor(sw, d));
@@ -1338,7 +1391,19 @@ constexpr uint32_t kDecide = 32;  // columns between decision points after the t
 constexpr uint32_t kPend = 64;   // passed candidates a group of k_sw_pairs buffers before one atomic
 constexpr uint32_t kClaim = 32;  // work items a group of k_sw_pairs claims with one atomic, at most
 
-template <int R>
+// Intra-wavefront LDS hand-off: data one lane wrote is read by other lanes of the same wavefront next.
+// LDS operations of a wavefront execute in order, so no instruction is needed; the fences keep the
+// compiler from moving the accesses across the hand-off (without them the accesses are a data race
+// in the language's memory model).
+__device__ inline void wave_lds_handoff() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// DIAG: try the lower bounds on the seed diagonal before a sweep (default; MTSV_SW_DIAG=0 launches the
+// instantiation without them, which tests use to check that bounds and sweeps decide alike).
+template <int R, bool DIAG>
 __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     constexpr int GS = 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
@@ -1356,17 +1421,18 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
             uint32_t base = 0;
             if (gl == 0) base = atomicAdd(a.pass_count, kPend);
             base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
+            wave_lds_handoff();  // lane 0's buffered entries are read by the whole group
             for (uint32_t i = gl; i < kPend; i += GS) a.pass_list[base + i] = pend_buf[i];
+            wave_lds_handoff();  // ... before lane 0 overwrites them
             pend = 0;
         }
     };
     const uint32_t n_work = *a.wl_count;
-    const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
-                                               : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
+    const uint32_t maxc = a.maxc;  // max_candidates as a rank bound, clamped on the host
     const uint32_t ONE = 0x00010001u, TWO = 0x00020002u;
     // items per claim: large enough that the claims do not bound the kernel, small enough that the last
-    // claims of the launch stay balanced (about eight claims per group)
-    const uint32_t chunk = min(max(n_work / (gridDim.x * (256 / GS) * 8u), 4u), kClaim);
+    // claims of the launch stay balanced (about eight claims per group: claim_shift = log2(groups * 8))
+    const uint32_t chunk = min(max(n_work >> a.claim_shift, 4u), kClaim);
 
     uint32_t phase = PH_FETCH;
     uint32_t loc = 0, loc_end = 0;  // position inside the claimed slice
@@ -1450,6 +1516,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                                 // strand, usize wrap of index.rs:406 (2*ED > L: nothing can pass), ED, threshold L - 2*ED
                                 m[6] = (rs & 1) | (2ull * EDi > (uint64_t)Li ? 2u : 0u) | ((EDi & 0xffu) << 8) | (((Li - 2 * EDi) & 0xffu) << 16);
                             }
+                            wave_lds_handoff();  // every lane of the group reads the staged items
                         }
                         if (loc == loc_end) {
                             gf |= F_DRAINED;
@@ -1538,7 +1605,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         // and the local score is at least that.  mismatches <= ED  =>  score >= L - 2*ED.
                         const uint32_t Lq = Lh(hf), EDq = (Lq - thrh(hf)) / 2;
                         bool decided = false;
-                        if (EDq + Lq <= lim && !(a.flags & 1u)) {
+                        if (DIAG && EDq + Lq <= lim) {
                             const int pad = (int)(GS * R) - (int)Lq;
                             // the lane's R window symbols on that diagonal (and its two neighbours): aligned dwords +
                             // v_alignbyte; sy[d] faces read position p with window column ED + p + d - 1
@@ -1568,7 +1635,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                                 }
                             }
                             const int mm0 = row_sum16(mm[1]);
-                            decided = (uint32_t)mm0 <= EDq && !(a.flags & 4u);
+                            decided = (uint32_t)mm0 <= EDq;
                             // One gap: read rows of the lanes below s on the diagonal, the rest on a neighbouring one
                             // (a base missing from the read, or an extra one), joined by a gap of one.  That alignment
                             // scores at least L - 2 - 2*mismatches, so mismatches <= ED - 1 still proves the
@@ -1591,7 +1658,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                                     best_mm = min(best_mm, pre - mm[1] + suf);
                                 }
                                 best_mm = -row_max16(-best_mm);
-                                decided = best_mm <= (int)EDq - 1 && !(a.flags & 4u);
+                                decided = best_mm <= (int)EDq - 1;
                             }
                         }
                         if (decided) {
@@ -1764,6 +1831,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         uint32_t base = 0;
         if (gl == 0) base = atomicAdd(a.pass_count, pend);
         base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
+        wave_lds_handoff();
         for (uint32_t i = gl; i < pend; i += GS) a.pass_list[base + i] = pend_buf[i];
     }
     unsigned long long v64 = gl == 0 ? verified : 0, w64 = gl == 0 ? wbytes : 0;
@@ -1831,8 +1899,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     __shared__ uint32_t eq_tab[5][W][256];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_work = *a.wl_count;
-    const uint32_t maxc = a.max_candidates < 0 ? 0xffffffffu
-                                               : (a.max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)a.max_candidates);
+    const uint32_t maxc = a.maxc;  // max_candidates as a rank bound, clamped on the host
     const uint32_t lane = lane_id();
     const uint32_t* bases32 = reinterpret_cast<const uint32_t*>(a.bases);
     unsigned long long verified = 0, wbytes = 0;
@@ -2063,6 +2130,10 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t n_strands, uint64_t r0,
 // launchers
 // ---------------------------------------------------------------------------------------------
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+// --max-candidates as a bound on candidate ranks (index.rs:385-389): None = no bound
+static inline uint32_t rank_bound(int64_t max_candidates) {
+    return max_candidates < 0 ? 0xffffffffu : (max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)max_candidates);
+}
 
 void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end) {
     begin &= ~15ull;  // whole 16-byte groups (a neighbouring range may write the same codes into a shared group)
@@ -2126,7 +2197,7 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     a.r0 = r0;
     a.edit_rate = edit_rate;
     a.min_seed = min_seed;
-    a.maxc = max_candidates < 0 ? 0xffffffffu : (max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)max_candidates);
+    a.maxc = rank_bound(max_candidates);
     a.strand_off = strand_off;
     a.strand_nseeds = strand_nseeds;
     a.hit_ref = hit_ref;
@@ -2146,7 +2217,9 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                        heavy_list, heavy_count);
 }
 
-void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
+void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len) {
+    EvalArgs a = a_;
+    a.maxc = rank_bound(a.max_candidates);
     // persistent 16-lane groups claim candidates from the worklist
 #define EVAL_CASE(RR, WW, GG) hipLaunchKernelGGL((k_evaluate<RR, WW, GG>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256 / GG), 256 * 8))), dim3(256), 0, s, ix, a)
     // (8-lane groups, 19 rows per lane, were measured slower for 150-base reads: 21.2 vs 19.2 ms per 1 M reads;
@@ -2160,17 +2233,61 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
     else if (max_len <= 208) EVAL_CASE(13, false, 16);
     else if (max_len < 254) EVAL_CASE(16, false, 16);
     else if (max_len <= 256) EVAL_CASE(16, true, 16);
-    else if (max_len <= 320) EVAL_CASE(20, true, 16);
-    else if (max_len <= 384) EVAL_CASE(24, true, 16);
-    else EVAL_CASE(32, true, 16);
+    else if (max_len <= kMaxRegisterReadLen) EVAL_CASE(20, true, 16);
+    else throw std::runtime_error("internal: launch_evaluate called for a read beyond the register-resident kernels");
 #undef EVAL_CASE
 }
 
-void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len) {
+// longest candidate window of a pass (the tiled kernel's strips are sized from it)
+namespace {
+__global__ __launch_bounds__(256) void k_max_window(uint32_t n_strands, const uint32_t* __restrict__ strand_off,
+                                                    const uint32_t* __restrict__ strand_ncand, const uint4* __restrict__ cand,
+                                                    unsigned long long* __restrict__ out) {
+    const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
+    uint32_t m = 0;
+    if (rs < n_strands) {
+        const uint32_t o = strand_off[rs], nc = strand_ncand[rs];
+        for (uint32_t i = 0; i < nc; i++) {
+            const uint4 c = cand[o + i];
+            m = max(m, c.y - c.x);
+        }
+    }
+    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, d));
+    if (lane_id() == 0 && m) atomicMax(out, (unsigned long long)m);
+}
+}  // namespace
+
+void launch_max_window(hipStream_t s, uint32_t n_strands, const uint32_t* strand_off, const uint32_t* strand_ncand,
+                       const uint4* cand, unsigned long long* out) {
+    hipLaunchKernelGGL(k_max_window, dim3(cdiv(n_strands, 256)), dim3(256), 0, s, n_strands, strand_off, strand_ncand, cand, out);
+}
+
+uint32_t tiled_groups(uint64_t max_items, uint32_t strip_len) {
+    // at most 1 GiB of strips (8 bytes per window column per group)
+    const uint64_t by_mem = std::max<uint64_t>(1, (1ull << 30) / (16ull * 8 * std::max<uint32_t>(strip_len, 1)));
+    const uint32_t blocks = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint64_t>(cdiv(max_items, 16), 256 * 2), by_mem));
+    return blocks * 16;
+}
+
+void launch_evaluate_tiled(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items) {
+    EvalArgs a = a_;
+    a.maxc = rank_bound(a.max_candidates);
+    const uint32_t blocks = tiled_groups(max_items, a.strip_len) / 16;
+    hipLaunchKernelGGL((k_evaluate<16, true, 16, true>), dim3(blocks), dim3(256), 0, s, ix, a);
+}
+
+void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len, bool diag) {
     // persistent 16-lane groups, two candidates per group: one resident generation of blocks pulls the worklist
+    EvalArgs a = a_;
+    a.maxc = rank_bound(a.max_candidates);
 #define SW_CASE(RR)                                                                                                      \
-    hipLaunchKernelGGL((k_sw_pairs<RR>), dim3(std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 3 : kSwOcc)))), \
-                       dim3(256), 0, s, ix, a)
+    do {                                                                                                                 \
+        const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 3 : kSwOcc))); \
+        a.claim_shift = 0;                                                                                               \
+        while ((1ull << a.claim_shift) < (uint64_t)grid * 16 * 8) a.claim_shift++;                                       \
+        if (diag) hipLaunchKernelGGL((k_sw_pairs<RR, true>), dim3(grid), dim3(256), 0, s, ix, a);                        \
+        else hipLaunchKernelGGL((k_sw_pairs<RR, false>), dim3(grid), dim3(256), 0, s, ix, a);                            \
+    } while (0)
     if (max_len <= 64) SW_CASE(4);
     else if (max_len <= 96) SW_CASE(6);
     else if (max_len <= 128) SW_CASE(8);
@@ -2180,8 +2297,10 @@ void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
 #undef SW_CASE
 }
 
-void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
+void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len,
                        bool list_mode) {
+    EvalArgs a = a_;
+    a.maxc = rank_bound(a.max_candidates);
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256), 256 * 8));
     uint32_t W = (max_len + 31) / 32;
 #define MYERS_CASE(WW)                                                                                   \

@@ -41,11 +41,16 @@ struct EvalArgs {
     uint32_t* pass_count = nullptr;
     uint32_t* next_list = nullptr;
     uint32_t* next_count = nullptr;
-    uint32_t flags = 0;  // k_sw_pairs, for measurements: bit 0 skips the diagonal lower bound (MTSV_SW_DIAG=0),
-                         // bit 2 computes it but never acts on it
+    // tiled long-read kernel: one strip of strip_len window columns per 16-lane group (bottom row of a band)
+    uint2* strip = nullptr;
+    uint32_t strip_len = 0;
+    // filled in by the launchers
+    uint32_t maxc = 0xffffffffu;  // max_candidates as a bound on candidate ranks
+    uint32_t claim_shift = 0;     // k_sw_pairs: work items per claim = clamp(n_work >> claim_shift, 4, 32)
 };
 
-constexpr uint32_t kMaxReadLen = 512;  // 16 lanes x 32 read rows per lane in k_evaluate
+constexpr uint32_t kMaxRegisterReadLen = 320;  // 16 lanes x 20 read rows per lane: k_evaluate with the matrix band in registers
+constexpr uint32_t kMaxReadLen = 32767;        // the tiled kernel's packed 16-bit cells (edit distance <= read length)
 
 // base normalisation of bytes [begin, end) of a read buffer, src -> dst (may be equal): every other kernel expects codes
 void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end);
@@ -69,11 +74,19 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                      uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, uint32_t* heavy_list,
                      uint32_t* heavy_count, unsigned long long* n_cand_total);
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
+// reads of kMaxRegisterReadLen + 1 .. kMaxReadLen bases: the same sweep in bands of 256 rows (a.strip / a.strip_len set:
+// tiled_groups(max_items, strip_len) strips of strip_len uint2 each, strip_len >= the pass's longest window)
+void launch_evaluate_tiled(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items);
+uint32_t tiled_groups(uint64_t max_items, uint32_t strip_len);
+void launch_max_window(hipStream_t s, uint32_t n_strands, const uint32_t* strand_off, const uint32_t* strand_ncand,
+                       const uint4* cand, unsigned long long* out);
 // edit-first order (reads up to 253 bases): Myers bit-vector edit distance, lane per candidate
 void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
                        bool list_mode = false);
 // reference order for reads <= 253 bases: SW prefilter alone, two candidates per 16-lane group
-void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
+// diag = false: without the lower bounds on the seed diagonal (every candidate that is not hopeless is swept)
+void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
+                     bool diag = true);
 void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,
                     const uint32_t* strand_off, const uint32_t* strand_ncand, const uint32_t* cand_status, uint4* out,
                     uint32_t* strand_nout);

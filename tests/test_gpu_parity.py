@@ -194,12 +194,13 @@ def test_batch_split_when_hit_workspace_is_small(tricky):
     st = b.stats()
     assert st["n_passes"] > 1
     assert_same_hits(b.download(), want)
-    # a workspace that cannot hold a single read's seed hits fails loudly
+    # a workspace that cannot hold a single read's seed hits is grown for that read (passes of one read)
     b2 = M.Batch(ix, 0, len(reads), len(bases), max_hits_ws=64)
     b2.upload(bases, off)
-    with pytest.raises(M.MtsvError) as e:
-        b2.run(mp)
-    assert e.value.code == _lib.E_DEVICE
+    b2.run(mp)
+    assert b2.stats()["n_passes"] > 100
+    assert_same_hits(b2.download(), want)
+    b2.close()
 
 
 def test_run_host_slices_match_oracle(tricky):
@@ -249,7 +250,7 @@ def test_run_host_errors_surface_from_the_uploader(small_db):
 def test_limits_and_argument_errors(small_db):
     ix, _ = small_db
     ix.to_device(0)
-    bases, off = helpers.reads_to_batch([b"ACGT" * 150])  # 600 bases > 512
+    bases, off = helpers.reads_to_batch([b"ACGT" * 10000])  # 40000 bases: beyond the 16-bit cells of the tiled kernel
     with pytest.raises(M.MtsvError) as e:
         ix.bin_batch(bases, off, device=0)
     assert e.value.code == _lib.E_LIMIT
@@ -261,7 +262,7 @@ def test_limits_and_argument_errors(small_db):
     assert len(ix.bin_batch(np.zeros(0, np.uint8), np.zeros(1, np.uint64), device=0)) == 0  # empty batch
 
 
-@pytest.mark.parametrize("read_len", [254, 300, 400, 512])
+@pytest.mark.parametrize("read_len", [254, 300, 320, 321, 400, 512, 513, 700, 1400])
 def test_long_reads_take_the_ssw_word_kernel_path(tricky, read_len):
     """reads of 254+ bases whose score reaches 254 make ssw_align rerun sw_sse2_word (ssw.c:789-792),
     whose lazy-F loop truncates vertical gaps at stripe boundaries: insertions planted there"""
@@ -295,6 +296,46 @@ def test_long_reads_take_the_ssw_word_kernel_path(tricky, read_len):
         want, _ = orc.bin_batch(bases, off, op, threads=8)
         assert len(want) > 20
         assert_same_hits(got, want)
+
+
+def test_stray_long_reads_do_not_fail_the_batch(tricky):
+    """The reference has no read-length cap (index.rs:258-432; ssw.c handles any length): a few long reads
+    (merged pairs, contigs) among short ones run in passes of their own through the tiled kernel and every
+    other read keeps its hits; host-sliced and resident paths agree with the oracle."""
+    ix, orc, short_reads = tricky
+    entries, gene, unit = helpers.tricky_db(seed=7)
+    rng = random.Random(99)
+    texts = [e[2].upper() for e in entries if len(e[2]) > 1200]
+    reads = list(short_reads[:400])
+    strays = []
+    for L in (321, 513, 800, 1100, 1100, 2 * 97 * 6):
+        t = rng.choice(texts)
+        st = rng.randrange(0, len(t) - min(L, len(t) - 1))
+        r = helpers.mutate(rng, t[st:st + L], rng.randrange(0, 12))
+        strays.append(r if rng.random() < 0.5 else helpers.revcomp(r))
+    strays.append(helpers.mutate(rng, unit * 12, 5))   # long read inside the tandem repeat: thousands of seed hits
+    strays.append(helpers.rnd_seq(rng, 900))           # long read without an origin
+    strays.append(b"N" * 700)
+    for k, r in enumerate(strays):  # first, last, adjacent and scattered positions
+        reads.insert([0, len(reads), 7, 8, 150, 151, 152, 300, 301][k] if k < 9 else rng.randrange(len(reads)), r)
+    bases, off = helpers.reads_to_batch(reads)
+    assert max(len(r) for r in reads) > 1000
+    mp, op = both_params()
+    ix.to_device(0)
+    want, _ = orc.bin_batch(bases, off, op, threads=8)
+    long_idx = [i for i, r in enumerate(reads) if len(r) > 320]
+    assert len(set(want["read"]) & set(long_idx)) >= 4  # the long reads do produce hits
+    got = ix.bin_batch(bases, off, mp, device=0)
+    assert_same_hits(got, want)
+    b = M.Batch(ix, 0, max_reads=64, max_bases=20000)  # sliced host path: long reads land in different slices
+    b.run_host(bases, off, mp)
+    assert_same_hits(b.download(), want)
+    b.close()
+    b = M.Batch(ix, 0, max_reads=len(reads), max_bases=len(bases), max_hits_ws=1 << 12)  # tiny hit workspace: grown for the repeat read
+    b.upload(bases, off)
+    b.run(mp)
+    assert_same_hits(b.download(), want)
+    b.close()
 
 
 def test_repeated_calls_with_changing_batch_shapes(small_db):
