@@ -4,10 +4,12 @@
     python bench.py --gpus 1 --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-A "step" is one pass of the whole hot path (seed search -> locate -> coalesce -> SW + edit verify
--> hit gather) over one batch of synthetic reads that is already resident in HBM; the index is
-replicated per GPU and reads shard across ranks with no collective on the data path (weak
-scaling: every rank processes its own batch of the same size).  Rank 0 prints ONE JSON line.
+A "step" is one pass of the whole hot path (H2D of the reads -> seed search -> locate -> coalesce ->
+SW + edit verify -> hit gather -> D2H of the hits) over one batch of synthetic reads handed over in
+host memory, as SURVEY.md 8(d) defines the metric; the index is resident in HBM, replicated per GPU,
+and reads shard across ranks with no collective on the data path (weak scaling: every rank processes
+its own batch of the same size).  The device-resident rate of the same kernels is reported beside it
+(`device_resident`).  Rank 0 prints ONE JSON line.
 
 Default workload = the configuration BASELINE.json's metric is quoted on: config2.
 Workloads (BASELINE.json configs; generators of SURVEY.md 8(d), seeds fixed):
@@ -61,7 +63,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (the box's CPU share of one GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
-                    help="skip the PCIe-inclusive leg and the other verify order (profiling runs: only the timed passes launch kernels)")
+                    help="skip the device-resident leg and the other verify order (profiling runs)")
     ap.add_argument("--verify-mode", type=int, default=0, help="0: reference order (SW + edit per candidate), 1: edit first")
     ap.add_argument("--dev-flags", type=int, default=0, help="MTSV_DEV_* flags (1: sampled SA only, 2: no k-mer table)")
     args = ap.parse_args()
@@ -137,64 +139,87 @@ def main():
     t_upload = time.time() - t0
     info = ix.info()
 
-    # ---- reads: each rank its own shard (different seed), resident in HBM before timing ----
+    # ---- reads: each rank its own shard (different seed), in host memory ----
+    import ctypes
+    from mtsv_tools_amd import _lib as L
     bases, off = M.synth_reads(ix, seed=1000 + rank, n_reads=n_reads, read_len=read_len)
     params = M.default_params()
-    batch = M.Batch(ix, local_rank, n_reads, len(bases))
-    batch.set_verify_mode(args.verify_mode)
-    t0 = time.time()
-    batch.upload(bases, off)
-    t_h2d = time.time() - t0
+    HIT_FIELDS = ("read", "tax_id", "gi", "edit", "strand", "offset")
+
+    def same_hits(a, b):
+        return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in HIT_FIELDS)
+
+    # ---- timed region = SURVEY 8(d): host bases in -> host hits out, through the C ABI ----
+    # (mtsv_batch_run_host + mtsv_batch_download = what mtsv_bin_batch does on its cached workspace: the reads are
+    # staged through pinned memory in slices, the slices run on the workspace's lanes, the hits arrive in pooled
+    # pinned memory; the workspace is the one mtsv_bin_batch would create for this batch)
+    slice_reads = int(os.environ.get("MTSV_BENCH_SLICE", 0)) or M.bin_batch_slice_reads(n_reads)
+    hb = M.Batch(ix, local_rank, min(n_reads, slice_reads), min(len(bases), slice_reads * (read_len + 8)))
+    hb.set_verify_mode(args.verify_mode)
+    bases_p, off_p = bases.ctypes.data, off.ctypes.data
+
+    def host_step(keep=False):
+        L._check(M.lib().mtsv_batch_run_host(hb.h, bases_p, off_p, n_reads, ctypes.byref(params)))
+        out_p, out_n = ctypes.c_void_p(), ctypes.c_uint64()
+        L._check(M.lib().mtsv_batch_download(hb.h, ctypes.byref(out_p), ctypes.byref(out_n)))
+        if keep:
+            return L._hits_from(out_p, out_n.value)  # copies, then frees
+        M.lib().mtsv_hits_free(out_p)
+        return None
 
     for _ in range(args.warmup):
-        batch.run(params)
+        host_step()
     barrier()
-    stage_acc = None
     t0 = time.perf_counter()
+    host_stage = None
     for _ in range(args.steps):
-        batch.run(params)
-        st = batch.stats()
-        if stage_acc is None:
-            stage_acc = dict(st["stage_ms"])
+        host_step()
+        sth = hb.stats()
+        if host_stage is None:
+            host_stage = dict(sth["stage_ms"])
         else:
-            for k, v in st["stage_ms"].items():
-                stage_acc[k] += v
+            for k, v in sth["stage_ms"].items():
+                host_stage[k] += v
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    st_host = hb.stats()
+    hits = host_step(keep=True)  # untimed: the hits the parity checks below look at
+    hb.close()
 
-    st = batch.stats()
-    hits = batch.download()
-    t0 = time.time()
-    # host buffers in, host hits out (what mtsv_bin_batch does): 1 Mi-read slices, copy of slice k+1
-    # overlapped with the kernels of slice k
-    slice_reads = int(os.environ.get("MTSV_BENCH_SLICE", 1 << 20))  # what mtsv_bin_batch uses
-    batch_pcie = (M.Batch(ix, local_rank, min(n_reads, slice_reads), min(len(bases), slice_reads * (read_len + 8)))
-                  if rank == 0 and not args.no_extras else None)
-    pcie_rate = None
-    if batch_pcie is not None:
-        batch_pcie.set_verify_mode(args.verify_mode)
-        # once untimed: the workspace's second input buffer and pinned staging are allocated on first use and kept
-        # (mtsv_bin_batch keeps its workspace between calls the same way)
-        batch_pcie.run_host(bases, off, params)
-        import ctypes
-        from mtsv_tools_amd import _lib as L
-        out_p, out_n = ctypes.c_void_p(), ctypes.c_uint64()
-        t0 = time.perf_counter()   # clock around the two C-ABI calls only (host bases in -> malloc'd host hits out)
-        batch_pcie.run_host(bases, off, params)
-        L._check(M.lib().mtsv_batch_download(batch_pcie.h, ctypes.byref(out_p), ctypes.byref(out_n)))
-        pcie_rate = n_reads / (time.perf_counter() - t0)
-        pcie_hits = L._hits_from(out_p, out_n.value)
-        batch_pcie.close()
-        if len(pcie_hits) != len(hits) or not all(np.array_equal(pcie_hits[f], hits[f]) for f in ("read", "tax_id", "edit", "strand", "offset")):
-            raise SystemExit("bench: sliced host path returned different hits")
-        del pcie_hits
-    # the other evaluation order of the two acceptance predicates, for information (never `value`)
+    if rank != 0:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- device-resident rate (reads already in HBM, hits left there): the kernels alone, for the roofline ----
+    resident = None
     alt = None
-    if rank == 0 and not args.no_extras:
+    stage_ms = None
+    stage_note = None
+    overlapped = None
+    st = st_host
+    if not args.no_extras:
+        batch = M.Batch(ix, local_rank, n_reads, len(bases))
+        batch.set_verify_mode(args.verify_mode)
+        batch.upload(bases, off)
+        batch.run(params)
+        t1 = time.perf_counter()
+        for _ in range(3):
+            batch.run(params)
+        res_dt = (time.perf_counter() - t1) / 3
+        st = batch.stats()
+        res_hits = batch.download()
+        if not same_hits(res_hits, hits):
+            raise SystemExit("bench: resident path and host path returned different hits")
+        resident = {"reads_per_s": n_reads / res_dt, "ms_per_step": res_dt * 1e3, "n_lanes": st.get("n_lanes", 1),
+                    "note": "mtsv_batch_run on reads already in HBM, hits left in HBM (3 runs after 1 warm-up); not `value`"}
+        del res_hits
+        # the other evaluation order of the two acceptance predicates, for information (never `value`)
         other = 1 - args.verify_mode
         batch.set_verify_mode(other)
         batch.run(params)
@@ -203,37 +228,30 @@ def main():
             batch.run(params)
         alt_dt = time.perf_counter() - t1
         alt_hits = batch.download()
-        alt = {"verify_mode": ["reference", "edit_first"][other], "reads_per_s": 3 * n_reads / alt_dt,
-               "stage_ms": batch.stats()["stage_ms"],
-               "hits_identical_to_timed_mode": bool(len(alt_hits) == len(hits) and all(np.array_equal(alt_hits[f], hits[f]) for f in ("read", "tax_id", "gi", "edit", "strand", "offset")))}
-
-    if rank != 0:
-        if world > 1:
-            dist.barrier()
-            dist.destroy_process_group()
-        return
+        alt = {"verify_mode": ["reference", "edit_first"][other], "device_resident_reads_per_s": 3 * n_reads / alt_dt,
+               "stage_ms": batch.stats()["stage_ms"], "hits_identical_to_timed_mode": bool(same_hits(alt_hits, hits))}
+        if not alt["hits_identical_to_timed_mode"]:
+            raise SystemExit("bench: the two verification orders returned different hits")
+        del alt_hits
+        batch.close()
+    # per-stage kernel times: one untimed pass of the same reads through a single-lane workspace, so that a
+    # stage's HIP-event span holds its own kernels only (the timed steps overlap lanes)
+    os.environ["MTSV_LANES"] = "1"
+    b1 = M.Batch(ix, local_rank, n_reads, len(bases))
+    del os.environ["MTSV_LANES"]
+    b1.set_verify_mode(args.verify_mode)
+    b1.upload(bases, off)
+    b1.run(params)
+    b1.run(params)
+    st1 = b1.stats()
+    stage_ms = dict(st1["stage_ms"])
+    b1.close()
+    stage_note = ("HIP events on the lane's own stream; one untimed pass of the same reads through a single-lane resident "
+                  f"workspace (MTSV_LANES=1); the timed steps ran {st_host.get('n_lanes', 1)} overlapping lanes over host slices")
+    overlapped = {"n_lanes": st_host.get("n_lanes", 1), "stage_ms_summed_over_lanes_per_step": {k: v / args.steps for k, v in host_stage.items()}}
 
     value = n_reads * args.steps * world / elapsed
     step_ms = elapsed / args.steps * 1e3
-    stage_ms = {k: v / args.steps for k, v in stage_acc.items()}
-    stage_note = "HIP events on the batch's stream, one lane"
-    overlapped = None
-    if st.get("n_lanes", 1) > 1:
-        # The timed batch ran as concurrent lanes: its stage times are sums over overlapping kernels.  For the
-        # per-stage table run the same reads once more through a single-lane workspace (untimed).
-        overlapped = {"n_lanes": st["n_lanes"], "stage_ms_summed_over_lanes": stage_ms}
-        batch.close()
-        os.environ["MTSV_LANES"] = "1"
-        b1 = M.Batch(ix, local_rank, n_reads, len(bases))
-        del os.environ["MTSV_LANES"]
-        b1.set_verify_mode(args.verify_mode)
-        b1.upload(bases, off)
-        b1.run(params)
-        b1.run(params)
-        stage_ms = dict(b1.stats()["stage_ms"])
-        b1.close()
-        stage_note = ("one untimed pass of the same reads through a single-lane workspace (MTSV_LANES=1); the timed "
-                      f"steps ran {st['n_lanes']} overlapping lanes, see ms_per_step")
 
     # ---- CPU baseline + algorithmic-byte counters from the oracle on a bounded sample ----
     cpu = None
@@ -262,48 +280,66 @@ def main():
                                             ("read", "tax_id", "gi", "edit", "strand", "offset"))
         parity = f"{'identical' if same else 'MISMATCH'} on {ns} sampled reads ({len(ohits)} hits)"
 
+    if "MISMATCH" in parity:
+        print(json.dumps({"error": "parity", "parity": parity}))
+        raise SystemExit("bench: GPU hits differ from the oracle's: " + parity)
+
     # ---- roofline ----
-    # achieved = algorithmic bytes / time against the HBM peak.  Primary figure: the whole
-    # pipeline (what `value` is made of).  The per-stage table prices every kernel with its own
-    # algorithmic bytes; the dominant kernel is named with its share of the step.
-    verify_name = ("k_edit_myers (+k_resolve)" if args.verify_mode == 1 else
-                   "k_sw_pairs + k_edit_myers (+k_resolve)" if read_len <= 253 else "k_evaluate (+k_resolve)")
-    kernel_stage = {"search": "k_search", "locate": "k_locate", "verify": verify_name,
-                    "coalesce": "k_coalesce", "expand": "k_expand", "thin_scan": "k_thin+scan", "gather": "scan+k_gather"}
+    # The dominant kernel is the SW prefilter k_sw_pairs (reference order, reads <= 253 bases).  It is bound by
+    # integer VALU issue, not by HBM: priced against the measured issue ceiling of the chip
+    # (profiles/r01_valu_issue_rate.txt: ~540 wave-instructions/us/SIMD for every integer op, 1024 SIMDs) with
+    # the USEFUL work only -- the packed 7-instruction recurrence of every DP cell pair the sweeps computed
+    # (device counter sw_cell_pairs; four 16-lane groups share one wave instruction) -- over its launch time
+    # (HIP events on the lane's stream, single-lane pass).  Its HBM figure in the contract's form (SURVEY 8d
+    # algorithmic bytes W per read over the same duration) and the pipeline's measured HBM traffic sit beside it.
+    VALU_PEAK = 1024 * 540e6  # wave-instructions per second
+    sw_ms = st1.get("sw_prefilter_ms", 0.0)
     dom = max((k for k in stage_ms if k != "total"), key=lambda k: stage_ms[k])
-    roof = {"bound": "hbm", "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
-            "kernel": "pipeline (all stages of one step)", "ms": step_ms,
-            "dominant_kernel": {"name": kernel_stage.get(dom, dom), "ms": stage_ms[dom],
-                                "share_of_step": stage_ms[dom] / stage_ms["total"]}}
+    roof = {"bound": "valu", "kernel": "k_sw_pairs (SW prefilter, index.rs:401-406)", "achieved": None, "peak": VALU_PEAK / 1e9,
+            "unit": "G wave-instr/s", "frac": None, "traffic": None, "kernel_ms": sw_ms,
+            "share_of_resident_step": (sw_ms / stage_ms["total"]) if stage_ms.get("total") else None,
+            "peak_source": "tools/valu_rate.hip on this chip: 540 wave-instr/us/SIMD x 1024 SIMDs (profiles/r01_valu_issue_rate.txt)"}
+    if sw_ms > 0 and st1.get("sw_cell_pairs"):
+        useful = st1["sw_cell_pairs"] * 7 / 4.0
+        roof["achieved"] = useful / (sw_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / roof["peak"]
+        roof["useful_work"] = {"sw_cell_pairs": st1["sw_cell_pairs"], "valu_per_cell_pair": 7, "groups_per_wave": 4}
     if stage_bytes is not None:
-        pipe = stage_bytes["total"] * n_reads / (step_ms * 1e-3) / 1e9
-        roof["achieved"] = pipe
-        roof["frac"] = pipe / PEAK_HBM_GBS
-        roof["algorithmic_bytes_per_read"] = stage_bytes["total"]
+        res_ms = resident["ms_per_step"] if resident else stage_ms["total"]
+        hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
+               "algorithmic_bytes_per_read": stage_bytes["total"],
+               "algorithmic_GBs_timed_region": stage_bytes["total"] * n_reads / (step_ms * 1e-3) / 1e9,
+               "algorithmic_GBs_resident_step": stage_bytes["total"] * n_reads / (res_ms * 1e-3) / 1e9,
+               "note": "algorithmic bytes = what the reference's own layout must touch (SURVEY 8d); the resident k-mer table and "
+                       "full suffix array avoid most of them, so this is a work rate, not a fraction of any roof"}
+        if sw_ms > 0:
+            hbm["dominant_kernel"] = {"name": "k_sw_pairs", "algorithmic_bytes_per_read": stage_bytes["verify"],
+                                      "achieved": stage_bytes["verify"] * n_reads / (sw_ms * 1e-3) / 1e9,
+                                      "frac": stage_bytes["verify"] * n_reads / (sw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
         per_stage = {}
-        for st_name, key in (("search", "search"), ("locate", "locate"), ("expand", "locate"), ("verify", "verify"),
-                             ("gather", "gather")):
+        for st_name, key in (("search", "search"), ("locate", "locate"), ("expand", "locate"), ("gather", "gather")):
             if st_name == "expand" and stage_ms["locate"] > 0.05:
                 continue  # k_locate ran: the locate bytes belong to it
             if st_name == "locate" and stage_ms["locate"] <= 0.05:
                 continue
             ms = stage_ms[st_name]
             if ms > 0:
-                per_stage[kernel_stage[st_name]] = {"ms": ms, "algorithmic_bytes_per_read": stage_bytes[key],
-                                                    "achieved_GBs": stage_bytes[key] * n_reads / (ms * 1e-3) / 1e9}
-        roof["per_kernel"] = per_stage
-        roof["note"] = ("achieved = the survey's algorithmic bytes (what the reference's own layout must touch: 64 B per rank "
-                        "query, SURVEY 8d) over the measured step; the resident k-mer table and full suffix array avoid most "
-                        "of those accesses, so the fraction can exceed 1 -- `traffic` is the measured HBM traffic per step")
+                per_stage[st_name] = {"ms": ms, "algorithmic_bytes_per_read": stage_bytes[key],
+                                      "algorithmic_GBs": stage_bytes[key] * n_reads / (ms * 1e-3) / 1e9}
+        hbm["per_stage"] = per_stage
         tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
         if os.path.exists(tr):
             try:
                 t = json.load(open(tr))
                 if t.get("workload") == args.workload and t.get("dev_flags") == args.dev_flags:
-                    roof["traffic"] = t["hbm_bytes_per_step"]
-                    roof["traffic_source"] = t.get("source")
+                    # PMC counters of an earlier profiled run of this workload (rocprofv3 cannot wrap the driver's own run)
+                    hbm["measured_traffic_bytes_per_step"] = t["hbm_bytes_per_step"]
+                    hbm["measured_traffic_source"] = t.get("source")
+                    hbm["measured_frac_of_peak_resident_step"] = t["hbm_bytes_per_step"] / (res_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+                    roof["traffic"] = t.get("k_sw_pairs_bytes_per_step")
             except Exception:
                 pass
+        roof["hbm"] = hbm
 
     out = {
         "metric": "reads/sec (whole node), 150bp reads vs MG-index",
@@ -312,15 +348,19 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3,
+        "ms_per_step": step_ms,
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32/i16",
         "data": "synthetic",
+        "value_region": "SURVEY 8(d): wall clock over host bases in -> host hits out through the C ABI (mtsv_batch_run_host + "
+                        "mtsv_batch_download = mtsv_bin_batch on a warm workspace), H2D of reads and D2H of hits included; "
+                        "index load/upload excluded",
+        "device_resident": resident,
         "config": {"workload": f"{args.workload}: {desc}", "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                    "index_symbols": info["n"], "index_file_bytes": os.path.getsize(idx_path),
-                   "index_hbm_bytes": info["device_bytes"], "dev_flags": args.dev_flags,
+                   "index_hbm_bytes": info["device_bytes"], "dev_flags": args.dev_flags, "workspace_reads": min(n_reads, slice_reads),
                    "verify_mode": ["reference (SW prefilter + edit distance per verified candidate)", "edit_first"][args.verify_mode],
                    "parallelism": f"reads sharded x{world}, index replicated, no collective"},
         "roofline": roof,
@@ -329,13 +369,11 @@ def main():
         "stage_ms_note": stage_note,
         "overlapped_lanes": overlapped,
         "counters_per_read": ctr_per,
-        "device_counters": {k: st[k] for k in ("n_seed_slots", "n_seed_hits", "lf_steps", "n_candidates",
-                                                "n_verified", "window_bytes", "n_hits", "n_passes")},
+        "device_counters": {k: st1[k] for k in ("n_seed_slots", "n_seed_hits", "lf_steps", "n_candidates",
+                                                 "n_verified", "window_bytes", "n_hits", "n_passes", "sw_cell_pairs")},
         "parity": parity,
-        "pcie_inclusive_reads_per_s": pcie_rate,
         "other_verify_order": alt,
-        "setup_s": {"index_build": t_build, "index_file_reused": index_cached, "index_load": t_load, "index_pack_upload_accel": t_upload,
-                    "reads_h2d": t_h2d},
+        "setup_s": {"index_build": t_build, "index_file_reused": index_cached, "index_load": t_load, "index_pack_upload_accel": t_upload},
     }
     print(json.dumps(out))
     if world > 1:

@@ -99,6 +99,10 @@ typedef struct {
     uint64_t n_lanes;       /* concurrent parts the batch ran as (MTSV_LANES, default 3 for >= 98304 reads): with
                              * more than one, stage_ms[0..6] are device times summed over the overlapping parts
                              * and stage_ms[7] is the wall time of the run */
+    uint64_t sw_cell_pairs; /* k_sw_pairs: DP cell pairs its sweeps computed, per 16-lane group (one packed
+                             * 7-instruction recurrence each; 4 groups share a wave instruction) */
+    float sw_prefilter_ms;  /* device time of the k_sw_pairs launches (HIP events on the lane's stream), summed
+                             * over lanes like stage_ms; part of stage_ms[5] */
 } mtsv_batch_stats;
 
 const char *mtsv_last_error(void);
@@ -134,10 +138,30 @@ int mtsv_index_to_device(mtsv_index *ix, int hip_device, uint32_t flags);
 /* ---- the hot path ----------------------------------------------------------------------- */
 /* bases: concatenated raw read bytes (any case, any byte), read_off[n_reads+1].
  * *hits is ordered by (read, strand, rank order of the reference's candidate loop) and owned by
- * the caller (mtsv_hits_free). */
+ * the caller (mtsv_hits_free); the array is page-locked host memory from a pool the library
+ * recycles (the hits of each slice are copied there while later slices still compute). */
 int mtsv_bin_batch(mtsv_index *ix, int hip_device, const uint8_t *bases, const uint64_t *read_off,
                    uint64_t n_reads, const mtsv_params *params, mtsv_hit **hits, uint64_t *n_hits);
 void mtsv_hits_free(mtsv_hit *hits);
+/* ---- several GPUs of one node (no collective: reads are independent) --------
+ * Mode A -- the reference's single-index workflow (README.md:69-73) on several GPUs: the index is replicated
+ * on every listed device, the reads are cut into n_devices contiguous blocks, one host thread and workspace per
+ * entry, hits concatenated in read order (hit.read indexes the whole batch).  A device may be listed more than
+ * once (two workspaces on it).  Output identical to mtsv_bin_batch. */
+int mtsv_bin_batch_multi(mtsv_index *ix, const int *devices, int n_devices, const uint8_t *bases,
+                         const uint64_t *read_off, uint64_t n_reads, const mtsv_params *params,
+                         mtsv_hit **hits, uint64_t *n_hits);
+/* Mode B -- the chunked-database workflow (mtsv-chunk, then one binner run per chunk, then mtsv-collapse:
+ * README.md:189, src/collapse.rs:597-625): chunk k of the database is resident on devices[k], every chunk sees
+ * every read, and the per-chunk hit lists are merged per read (chunk order within a read).
+ * mtsv_format_results on the merged list writes the line mtsv-collapse would produce from the per-chunk
+ * result files: smallest edit per (read, TaxId). */
+int mtsv_bin_batch_chunks(mtsv_index *const *chunks, const int *devices, int n_chunks,
+                          const uint8_t *bases, const uint64_t *read_off, uint64_t n_reads,
+                          const mtsv_params *params, mtsv_hit **hits, uint64_t *n_hits);
+/* reads per device workspace mtsv_bin_batch creates (and keeps) for a host batch of n_reads reads; larger
+ * batches stream through it in slices */
+uint64_t mtsv_bin_batch_workspace_reads(uint64_t n_reads);
 
 /* The same path with the batch resident in HBM (what bench.py times).  The index must already be
  * on `hip_device`.  max_hits_ws = seed-hit workspace entries (0 = default). */
@@ -151,6 +175,9 @@ int mtsv_batch_create(mtsv_index *ix, int hip_device, uint64_t max_reads, uint64
 #define MTSV_VERIFY_REFERENCE 0
 #define MTSV_VERIFY_EDIT_FIRST 1
 int mtsv_batch_set_verify_mode(mtsv_batch *b, int mode);
+/* process-wide default of workspaces created from now on (also those mtsv_bin_batch* keep); the environment
+ * variable, when set, wins */
+int mtsv_set_default_verify_mode(int mode);
 int mtsv_batch_upload(mtsv_batch *b, const uint8_t *bases, const uint64_t *read_off,
                       uint64_t n_reads);
 int mtsv_batch_run(mtsv_batch *b, const mtsv_params *params); /* synchronous: returns when done */

@@ -12,6 +12,9 @@ from ._lib import (  # noqa: F401
     MGIndex,
     MtsvError,
     Params,
+    bin_batch_chunks,
+    bin_batch_multi,
+    bin_batch_slice_reads,
     default_params,
     device_count,
     format_results,

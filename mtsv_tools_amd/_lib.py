@@ -40,7 +40,7 @@ class BatchStats(C.Structure):  # mtsv_batch_stats
                 ("n_seed_slots", C.c_uint64), ("n_seed_hits", C.c_uint64), ("lf_steps", C.c_uint64),
                 ("n_candidates", C.c_uint64), ("n_verified", C.c_uint64),
                 ("window_bytes", C.c_uint64), ("n_hits", C.c_uint64), ("n_passes", C.c_uint64),
-                ("n_rounds", C.c_uint64), ("n_lanes", C.c_uint64)]
+                ("n_rounds", C.c_uint64), ("n_lanes", C.c_uint64), ("sw_cell_pairs", C.c_uint64), ("sw_prefilter_ms", C.c_float)]
 
     def as_dict(self):
         d = {n: int(getattr(self, n)) for n, _ in self._fields_[1:]}
@@ -59,7 +59,8 @@ EXPORTS = [
     "mtsv_index_info", "mtsv_index_free", "mtsv_set_build_device", "mtsv_index_to_device", "mtsv_bin_batch",
     "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run", "mtsv_batch_run_host",
     "mtsv_batch_stats_get", "mtsv_batch_set_verify_mode", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
-    "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads",
+    "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads", "mtsv_bin_batch_workspace_reads",
+    "mtsv_bin_batch_multi", "mtsv_bin_batch_chunks", "mtsv_set_default_verify_mode",
 ]
 
 _lib = None
@@ -90,6 +91,10 @@ def lib():
                                      C.POINTER(u64)]
         L.mtsv_hits_free.argtypes = [vp]
         L.mtsv_hits_free.restype = None
+        L.mtsv_bin_batch_multi.argtypes = [vp, vp, i32, vp, vp, u64, C.POINTER(Params), C.POINTER(vp), C.POINTER(u64)]
+        L.mtsv_bin_batch_chunks.argtypes = [vp, vp, i32, vp, vp, u64, C.POINTER(Params), C.POINTER(vp), C.POINTER(u64)]
+        L.mtsv_bin_batch_workspace_reads.argtypes = [u64]
+        L.mtsv_bin_batch_workspace_reads.restype = u64
         L.mtsv_batch_create.argtypes = [vp, i32, u64, u64, u64, C.POINTER(vp)]
         L.mtsv_batch_upload.argtypes = [vp, vp, vp, u64]
         L.mtsv_batch_run.argtypes = [vp, C.POINTER(Params)]
@@ -120,6 +125,36 @@ def version():
 
 def device_count():
     return lib().mtsv_device_count()
+
+
+def bin_batch_multi(index, devices, bases, read_off, params=None):
+    """mtsv_bin_batch_multi: one index replicated on `devices`, reads in contiguous blocks (Mode A)"""
+    params = params or default_params()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+    dev = (C.c_int * len(devices))(*devices)
+    out, n = C.c_void_p(), C.c_uint64()
+    _check(lib().mtsv_bin_batch_multi(index.h, dev, len(devices), bases.ctypes.data, read_off.ctypes.data,
+                                      len(read_off) - 1, C.byref(params), C.byref(out), C.byref(n)))
+    return _hits_from(out, n.value)
+
+
+def bin_batch_chunks(indexes, devices, bases, read_off, params=None):
+    """mtsv_bin_batch_chunks: chunk k of the database on devices[k], hit lists merged per read (Mode B)"""
+    params = params or default_params()
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
+    dev = (C.c_int * len(devices))(*devices)
+    hs = (C.c_void_p * len(indexes))(*[ix.h for ix in indexes])
+    out, n = C.c_void_p(), C.c_uint64()
+    _check(lib().mtsv_bin_batch_chunks(hs, dev, len(indexes), bases.ctypes.data, read_off.ctypes.data,
+                                       len(read_off) - 1, C.byref(params), C.byref(out), C.byref(n)))
+    return _hits_from(out, n.value)
+
+
+def bin_batch_slice_reads(n_reads):
+    """reads per device workspace mtsv_bin_batch would create for a host batch of n_reads reads"""
+    return int(lib().mtsv_bin_batch_workspace_reads(n_reads))
 
 
 def set_build_device(device):

@@ -48,6 +48,8 @@ void dev_alloc(T** p, uint64_t count, uint64_t* bytes) {
 }
 }  // namespace
 
+int g_default_verify_mode = MTSV_VERIFY_REFERENCE;
+
 constexpr uint64_t kLaneMinReads = 32768;  // a lane below this many reads does not fill the device
 constexpr uint64_t kChunkMaxReads = 4ull << 20;  // lanes take a range in chunks of at most this many reads (smaller chunks measured slower: per-pass launches and host round trips)
 
@@ -93,6 +95,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     HIP_CHECK(hipHostMalloc((void**)&h_counters, kCounters * sizeof(uint64_t)));
     if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
     if (const char* e = getenv("MTSV_SW_DIAG")) sw_diag = atoi(e) != 0;
+    verify_mode = g_default_verify_mode;
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
     for (int k = 1; k < n_lanes; k++) {
@@ -184,6 +187,7 @@ void Batch::reset_lane() {
     HIP_CHECK(hipSetDevice(di->device));
     memset(&stats, 0, sizeof stats);
     memset(stage_acc, 0, sizeof stage_acc);
+    sw_ms_acc = 0;
     n_hits_total = 0;
     HIP_CHECK(hipMemsetAsync(d_counters, 0, kCounters * sizeof(uint64_t), stream));
     HIP_CHECK(hipEventRecord(ev[8], stream));
@@ -191,9 +195,11 @@ void Batch::reset_lane() {
 
 void Batch::finish_lane() {
     HIP_CHECK(hipEventRecord(ev[9], stream));
-    HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, kCounters * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipEventElapsedTime(&stage_acc[7], ev[8], ev[9]));
+    stats.sw_cell_pairs = h_counters[14];
+    stats.sw_prefilter_ms = sw_ms_acc;
     stats.lf_steps = h_counters[2];
     stats.n_candidates = h_counters[3];
     stats.n_verified = h_counters[4];
@@ -237,6 +243,8 @@ void Batch::end_run() {
         stats.n_candidates += l->stats.n_candidates;
         stats.n_verified += l->stats.n_verified;
         stats.window_bytes += l->stats.window_bytes;
+        stats.sw_cell_pairs += l->stats.sw_cell_pairs;
+        stats.sw_prefilter_ms += l->stats.sw_prefilter_ms;
     }
     if (overlapped) stage_acc[7] = (float)wall_ms;
     for (int s = 0; s < MTSV_N_STAGES; s++) stats.stage_ms[s] = stage_acc[s];
@@ -424,6 +432,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             a.out = d_out;
             a.n_verified = (unsigned long long*)(d_counters + 4);
             a.window_bytes = (unsigned long long*)(d_counters + 5);
+            a.sw_columns = (unsigned long long*)(d_counters + 14);
             // one launch: a group whose candidate fails walks on to the next candidate of the same TaxId
             a.worklist = d_worklist;
             a.wl_count = (const uint32_t*)(d_counters + 1);
@@ -470,7 +479,9 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     sw.wl_cursor = (uint32_t*)(d_counters + 8);
                     sw.pass_list = pass_list;
                     sw.pass_count = (uint32_t*)(d_counters + 9);
+                    if (round == 0) HIP_CHECK(hipEventRecord(ev[10], stream));
                     launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag);
+                    if (round == 0) HIP_CHECK(hipEventRecord(ev[11], stream));
                     EvalArgs my = a;
                     my.worklist = pass_list;
                     my.wl_count = (const uint32_t*)(d_counters + 9);
@@ -480,6 +491,11 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     launch_edit_myers(stream, v, my, items, pass_max_len, true);
                     HIP_CHECK(hipMemcpyAsync(h_counters + 11, next_slot, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipStreamSynchronize(stream));
+                    if (round == 0) {
+                        float ms = 0;
+                        HIP_CHECK(hipEventElapsedTime(&ms, ev[10], ev[11]));
+                        sw_ms_acc += ms;
+                    }
                     const uint64_t n_next = h_counters[11] & 0xffffffffull;
                     if (n_next == 0) break;
                     stats.n_rounds++;
@@ -606,7 +622,7 @@ bool pinned_hits_release(void* p) { return p && pool().put(p); }
 // stream each -- pull ready slices in order and run the pipeline on them.  A finished slice's hits start
 // their way to the pinned result array at once, in slice order, on a third stream.  Nothing waits for a
 // whole batch: the steady state runs at max(kernels, staging, DMA).
-void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p) {
+void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p, uint64_t read_base) {
     HIP_CHECK(hipSetDevice(di->device));
     std::vector<Batch*> ls{this};
     for (auto& l : extra) ls.push_back(l.get());
@@ -670,8 +686,15 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     // cut the next slice: a short first one so the kernels start early, then full ones
                     s = cut_at;
                     k = slices.size();
+                    // Slice sizes ramp up from small ones (every lane has work after the first millisecond of
+                    // copying) and taper off towards the end of the batch (the lanes finish together).
                     uint64_t want = slice_reads;
-                    if (k < 3 && n > 2 * slice_reads) want = std::max<uint64_t>(slice_reads >> (3 - k), 4096);
+                    if (n > 2 * slice_reads) {
+                        const uint64_t lanes = ls.size(), floor_reads = std::min<uint64_t>(slice_reads, 96 << 10);
+                        const uint64_t up = floor_reads + s / lanes;                  // grows with the reads already cut
+                        const uint64_t down = std::max(floor_reads, (n - s) / (2 * lanes));  // shrinks with the reads left
+                        want = std::min(slice_reads, std::min(up, down));
+                    }
                     e = std::min(n, s + want);
                     if (read_off[e] < read_off[s]) throw std::runtime_error("arg: read_off is not ascending");
                     if (read_off[e] - read_off[s] > slice_bases) {  // largest e with at most slice_bases bases
@@ -704,7 +727,6 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     parallel_copy(rb.h_bases, bases + first, nb);
                     HIP_CHECK(hipMemcpyAsync(rb.d_bases, rb.h_bases, nb, hipMemcpyHostToDevice, cs));
                 }
-                launch_normalise(cs, rb.d_bases, rb.d_bases, 0, nb);  // in place: a slice is consumed once
                 HIP_CHECK(hipMemcpyAsync(rb.d_off, rb.h_off, (cnt + 1) * 4, hipMemcpyHostToDevice, cs));
                 const double t1 = now_s();
                 HIP_CHECK(hipStreamSynchronize(cs));
@@ -754,7 +776,10 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                 const RingBuf& rb = ring[k % NB];
                 const uint64_t before = lane->n_hits_total;
                 const double t0 = now_s();
-                lane->run_slice(p, rb.d_bases, rb.d_off, rb.h_off, sl.end - sl.begin, sl.max_len, sl.begin);
+                // base normalisation (binner.rs:88-100) in place, on the lane's own stream: a kernel on the copy
+                // stream would queue behind the persistent verification kernels of the other lanes
+                launch_normalise(lane->stream, rb.d_bases, rb.d_bases, 0, rb.h_off[sl.end - sl.begin]);
+                lane->run_slice(p, rb.d_bases, rb.d_off, rb.h_off, sl.end - sl.begin, sl.max_len, read_base + sl.begin);
                 if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms, done at %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3, (now_s() - run_t0) * 1e3);
                 {
                     std::lock_guard<std::mutex> lk(mu);
@@ -783,6 +808,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     lane_main(this);
     for (auto& t : th) t.join();
     commit_mu = nullptr;
+    if (trace) fprintf(stderr, "[run_host] threads joined at %.1f ms\n", (now_s() - run_t0) * 1e3);
     if (first_err) {
         (void)hipStreamSynchronize(copy_stream2);
         std::rethrow_exception(first_err);
@@ -790,6 +816,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     end_run();
     HIP_CHECK(hipStreamSynchronize(copy_stream2));
     staged_valid = staged_hits == total_hits;
+    if (trace) fprintf(stderr, "[run_host] hits on the host at %.1f ms (%llu slices)\n", (now_s() - run_t0) * 1e3, (unsigned long long)slices.size());
     if (!staged_valid) throw std::runtime_error("internal: run_host staged " + std::to_string(staged_hits) + " of " + std::to_string(total_hits) + " hits");
 }
 

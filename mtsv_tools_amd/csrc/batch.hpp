@@ -24,9 +24,9 @@ struct Batch {
         uint8_t* h_bases = nullptr;
         uint32_t* h_off = nullptr;
     };
-    static constexpr int kUploaders = 2;
+    static constexpr int kUploaders = 3;
     std::vector<RingBuf> ring;
-    hipStream_t copy_streams[kUploaders] = {nullptr, nullptr};
+    hipStream_t copy_streams[kUploaders] = {};
     std::mutex* commit_mu = nullptr;  // set while run_host's threads may touch the lanes' result arrays
     uint64_t max_reads, max_bases, hit_cap, hits_cap = 0;
     uint64_t bytes = 0;
@@ -64,7 +64,8 @@ struct Batch {
     uint2* d_strip = nullptr;  // tiled long-read kernel: band hand-over strips, allocated when a pass first needs them
     uint64_t strip_cap = 0;
     uint64_t* h_counters = nullptr;  // pinned
-    hipEvent_t ev[10];
+    hipEvent_t ev[12];  // [0..7] stage boundaries of a pass, [8..9] the lane's run, [10..11] around k_sw_pairs
+    float sw_ms_acc = 0;
 
     std::vector<uint32_t> h_read_off;
     uint32_t max_len = 0;
@@ -84,7 +85,8 @@ struct Batch {
 
     void upload(const uint8_t* bases, const uint64_t* read_off, uint64_t n);
     void run(const mtsv_params& p);
-    void run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p);
+    // read_base: added to the `read` field of every hit (a caller that shards one host batch over devices)
+    void run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p, uint64_t read_base = 0);
     void download(mtsv_hit** hits, uint64_t* n);
 
    private:
@@ -100,6 +102,8 @@ struct Batch {
                    uint32_t slice_max_len, uint64_t read_base);
     void end_run();
 };
+
+extern int g_default_verify_mode;  // mtsv_set_default_verify_mode
 
 // result arrays in pinned host memory, recycled through a pool (mtsv_hits_free returns them)
 mtsv_hit* pinned_hits_alloc(uint64_t n_hits, uint64_t* cap_hits);

@@ -2,10 +2,18 @@
 // libmtsv_amd: same flags and defaults (:26-113), same validation (:140-262), same exit codes
 // (0 ok, 2 query error, 3 no results path, 4 resume error, 11 write error, 12 read error;
 // invalid numbers abort like the reference's panics, exit 101), same results grammar
-// (src/binner.rs:310-379), same resume rule (:347-411).  Extras: --device, --batch-reads,
+// (src/binner.rs:310-379), same resume rule (:347-411).  Extras: --device / --devices, --batch-reads,
 // --parse-only (ingest check: prints record / base counts and checksums, needs no index or GPU).
 // The reads of a batch are processed on the GPU; result lines are written in input order (the
 // reference's order is unspecified: vendor/cue/src/lib.rs:67-74).
+//
+// Several GPUs of one node:
+//   --devices 0,1,..  with one --index: the index is loaded once and made resident on every listed device;
+//                     one worker thread and workspace per entry pulls read batches (README.md:69-73 workflow)
+//   --index a,b,..    the chunks of a database cut by mtsv-chunk, chunk k on the k-th listed device (round
+//                     robin): every chunk sees every batch and the hits are merged per read, so the one results
+//                     file equals what mtsv-collapse makes of the per-chunk files (README.md:189,
+//                     collapse.rs:597-625: smallest edit per read and TaxId)
 #include <zlib.h>
 
 #include <cerrno>
@@ -220,7 +228,7 @@ struct Args {
     std::string threads = "4", edit = "0.13", seed_size = "18", seed_interval = "15", min_seed = "0.015",
                 max_hits = "2000", tune_max_hits = "200", max_assign, max_cand, read_offset = "0";
     bool verbose = false, force = false, parse_only = false;
-    int device = 0;
+    std::vector<int> devices{0};
     uint64_t batch_reads = 1u << 20;
 };
 
@@ -280,13 +288,36 @@ int main(int argc, char** argv) {
         else if (key == "--output-format") a.output_format = val();
         else if (key == "--force-overwrite") a.force = true;
         else if (key == "-v") a.verbose = true;
-        else if (key == "--device") a.device = atoi(val().c_str());
-        else if (key == "--batch-reads") a.batch_reads = strtoull(val().c_str(), nullptr, 10);
+        else if (key == "--device" || key == "--devices") {
+            a.devices.clear();
+            const std::string v = val();
+            size_t at = 0;
+            while (at <= v.size()) {
+                size_t c = v.find(',', at);
+                if (c == std::string::npos) c = v.size();
+                const std::string tok = v.substr(at, c - at);
+                char* e = nullptr;
+                const long d = strtol(tok.c_str(), &e, 10);
+                if (tok.empty() || *e || d < 0 || d > 1023) usage_error("Invalid value for '" + key + "': a comma-separated list of GPU ordinals is expected");
+                a.devices.push_back((int)d);
+                at = c + 1;
+            }
+        } else if (key == "--batch-reads") {
+            const std::string v = val();
+            char* e = nullptr;
+            errno = 0;
+            const unsigned long long n = strtoull(v.c_str(), &e, 10);
+            if (v.empty() || v[0] == '-' || *e || errno || n < 1 || n > 0x7fffffffull)
+                usage_error("Invalid value for '--batch-reads <N>': a number of reads between 1 and 2147483647 is expected");
+            a.batch_reads = n;
+        }
         else if (key == "--parse-only") a.parse_only = true;
         else if (key == "-h" || key == "--help") {
             printf("mtsv-binner (MI355X) -- flags as the reference: --fasta|--fastq, -i/--index, -m/--results, -t/--threads,\n"
                    "-e/--edit-rate, --seed-size, --seed-interval, --min-seed, --max-hits, --tune-max-hits, --max-assignments,\n"
-                   "--max-candidates, --read-offset, --output-format default|long, --force-overwrite, -v; extras: --device N, --batch-reads N\n");
+                   "--max-candidates, --read-offset, --output-format default|long, --force-overwrite, -v;\n"
+                   "extras: --devices 0,1,.. (index replicated, reads shared out), --index a,b,.. (database chunks, one per GPU, hits merged),\n"
+                   "--batch-reads N, --parse-only\n");
             return 0;
         } else if (key == "-V" || key == "--version") {
             printf("mtsv 2.1.0 (%s)\n", mtsv_version());
@@ -494,20 +525,44 @@ int main(int argc, char** argv) {
         return 2;
     }
     logmsg("INFO", "Deserializing candidate filter ...");
-    mtsv_index* ix = nullptr;
-    if (mtsv_index_load(a.index.c_str(), &ix) != MTSV_OK || mtsv_index_to_device(ix, a.device, MTSV_DEV_DEFAULT) != MTSV_OK) {
-        logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
-        return 2;
+    std::vector<std::string> index_paths;
+    for (size_t at = 0; at <= a.index.size();) {
+        size_t c = a.index.find(',', at);
+        if (c == std::string::npos) c = a.index.size();
+        if (c > at) index_paths.push_back(a.index.substr(at, c - at));
+        at = c + 1;
+    }
+    if (index_paths.empty()) usage_error("The following required arguments were not provided: --index <INDEX>");
+    const bool chunked = index_paths.size() > 1;  // Mode B
+    // the two acceptance predicates are evaluated edit distance first (identical hits, about twice the device
+    // rate for reads up to 253 bases); MTSV_VERIFY=reference keeps the reference's order
+    if (!getenv("MTSV_VERIFY")) mtsv_set_default_verify_mode(MTSV_VERIFY_EDIT_FIRST);
+    std::vector<mtsv_index*> idx(index_paths.size(), nullptr);
+    std::vector<int> chunk_dev(index_paths.size(), 0);
+    for (size_t c = 0; c < index_paths.size(); c++) {
+        chunk_dev[c] = a.devices[c % a.devices.size()];
+        if (mtsv_index_load(index_paths[c].c_str(), &idx[c]) != MTSV_OK) {
+            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+            return 2;
+        }
+        // one index: resident on every listed device; chunks: chunk c on its device
+        for (size_t d = 0; d < (chunked ? 1 : a.devices.size()); d++)
+            if (mtsv_index_to_device(idx[c], chunked ? chunk_dev[c] : a.devices[d], MTSV_DEV_DEFAULT) != MTSV_OK) {
+                logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+                return 2;
+            }
     }
     logmsg("INFO", "Beginning queries.");
     struct timespec w0;
     clock_gettime(CLOCK_MONOTONIC, &w0);
 
-    // Three overlapped stages (the reference overlaps producer / workers / joiner the same way,
-    // vendor/cue/src/lib.rs:45-105): the producer parses FASTX into batches, this thread runs the
-    // batches on the GPU, a writer thread formats and writes the result lines in input order.
+    // Overlapped stages (the reference overlaps producer / workers / joiner the same way,
+    // vendor/cue/src/lib.rs:45-105): the producer parses FASTX into numbered batches, GPU workers (one per
+    // --devices entry; two dispatchers over all chunks in chunk mode) take batches as they come, a writer
+    // thread formats and writes the result lines in input order.
     struct Work {
         std::unique_ptr<ReadBlock> rb;
+        uint64_t seq = 0;
         mtsv_hit* hits = nullptr;
         uint64_t n_hits = 0;
     };
@@ -538,7 +593,10 @@ int main(int argc, char** argv) {
             cv.notify_all();
         }
     };
+    const size_t n_workers = chunked ? 2 : a.devices.size();
     Queue parsed, done;
+    parsed.cap = n_workers + 1;
+    done.cap = n_workers + 1;
     std::mutex err_mu;
     int exit_code = 0;
     auto set_code = [&](int c) {
@@ -550,11 +608,13 @@ int main(int argc, char** argv) {
         return exit_code != 0;
     };
 
+    uint64_t n_batches = 0;
     std::thread reader([&] {
         bool ok = produce(a.batch_reads, [&](std::unique_ptr<ReadBlock> rb) {
             if (failed()) return false;
             auto w = std::make_unique<Work>();
             w->rb = std::move(rb);
+            w->seq = n_batches++;
             parsed.push(std::move(w));
             return true;
         });
@@ -566,8 +626,26 @@ int main(int argc, char** argv) {
     });
 
     std::thread writer([&] {
-        uint64_t total = 0;
-        while (auto w = done.pop()) {
+        uint64_t total = 0, next_seq = 0;
+        std::vector<std::unique_ptr<Work>> held;  // batches that finished ahead of their turn
+        for (;;) {
+            std::unique_ptr<Work> w;
+            for (auto& h : held)
+                if (h && h->seq == next_seq) {
+                    w = std::move(h);
+                    h = std::move(held.back());
+                    held.pop_back();
+                    break;
+                }
+            if (!w) {
+                w = done.pop();
+                if (!w) break;
+                if (w->seq != next_seq) {
+                    held.push_back(std::move(w));
+                    continue;
+                }
+            }
+            next_seq++;
             // write_assignments over slices of the batch's hits (cut between reads), one thread each
             const uint64_t n_reads = w->rb->n();
             const unsigned parts = w->n_hits >= (1u << 16) ? host_threads : 1;
@@ -638,14 +716,40 @@ int main(int argc, char** argv) {
         }
     });
 
-    while (auto w = parsed.pop()) {
-        if (failed()) continue;  // drain
-        if (mtsv_bin_batch(ix, a.device, w->rb->bases.data(), w->rb->off.data(), w->rb->n(), &p, &w->hits, &w->n_hits) != MTSV_OK) {
-            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
-            set_code(2);
-            continue;
+    auto gpu_worker = [&](size_t wk) {
+        mtsv_batch* ws = nullptr;  // one index: this worker's own workspace on its device
+        while (auto w = parsed.pop()) {
+            if (failed()) continue;  // drain
+            int rc;
+            if (chunked) {
+                rc = mtsv_bin_batch_chunks(idx.data(), chunk_dev.data(), (int)idx.size(), w->rb->bases.data(), w->rb->off.data(), w->rb->n(), &p,
+                                           &w->hits, &w->n_hits);
+            } else {
+                const uint64_t nb = w->rb->bases.size(), nr = w->rb->n();
+                if (!ws) {
+                    const uint64_t ws_reads = mtsv_bin_batch_workspace_reads(a.batch_reads);
+                    // room for reads a third longer than this batch's before slices are cut by bases
+                    const uint64_t ws_bases = std::max<uint64_t>(1 << 22, (uint64_t)((double)nb / (double)std::max<uint64_t>(nr, 1) * (double)ws_reads * 1.33));
+                    rc = mtsv_batch_create(idx[0], a.devices[wk], ws_reads, ws_bases, 0, &ws);
+                } else
+                    rc = MTSV_OK;
+                if (rc == MTSV_OK) rc = mtsv_batch_run_host(ws, w->rb->bases.data(), w->rb->off.data(), nr, &p);
+                if (rc == MTSV_OK) rc = mtsv_batch_download(ws, &w->hits, &w->n_hits);
+            }
+            if (rc != MTSV_OK) {
+                logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+                set_code(2);
+                continue;
+            }
+            done.push(std::move(w));
         }
-        done.push(std::move(w));
+        if (ws) mtsv_batch_free(ws);
+    };
+    {
+        std::vector<std::thread> workers;
+        for (size_t wk = 1; wk < n_workers; wk++) workers.emplace_back(gpu_worker, wk);
+        gpu_worker(0);
+        for (auto& t : workers) t.join();
     }
     done.close();
     reader.join();
@@ -661,6 +765,6 @@ int main(int argc, char** argv) {
     snprintf(msg, sizeof msg, "All worker and result consumer threads terminated. Took %.3f seconds.",
              (w1.tv_sec - w0.tv_sec) + (w1.tv_nsec - w0.tv_nsec) * 1e-9);
     logmsg("INFO", msg);
-    mtsv_index_free(ix);
+    for (auto* ix : idx) mtsv_index_free(ix);
     return 0;
 }

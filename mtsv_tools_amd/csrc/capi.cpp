@@ -73,6 +73,41 @@ void par_for(uint64_t n, int threads, F fn) {
 }
 }  // namespace
 
+namespace {
+// run fn(k) for k in [0, n) on one thread each; the first failure (by k) is rethrown in the caller
+template <class F>
+void fork_join(int n, F fn) {
+    std::vector<std::string> err(n);
+    std::vector<char> bad(n, 0);
+    std::vector<std::thread> th;
+    auto body = [&](int k) {
+        try {
+            fn(k);
+        } catch (const std::exception& e) {
+            err[k] = e.what();
+            bad[k] = 1;
+        }
+    };
+    for (int k = 1; k < n; k++) th.emplace_back(body, k);
+    body(0);
+    for (auto& t : th) t.join();
+    for (int k = 0; k < n; k++)
+        if (bad[k]) throw std::runtime_error(err[k]);
+}
+// slot of entry k: how many earlier entries name the same device
+int slot_of(const int* devices, int k) {
+    int s = 0;
+    for (int j = 0; j < k; j++) s += devices[j] == devices[k];
+    return s;
+}
+void release_parts(std::vector<mtsv_hit*>& parts) {
+    for (auto*& p : parts) {
+        if (p && !mtsv::pinned_hits_release(p)) free(p);
+        p = nullptr;
+    }
+}
+}  // namespace
+
 extern "C" {
 
 const char* mtsv_last_error(void) { return g_err.c_str(); }
@@ -152,7 +187,7 @@ int mtsv_index_info(const mtsv_index* ix, mtsv_index_info_t* info) {
 
 void mtsv_index_free(mtsv_index* ix) {
     if (!ix) return;
-    for (auto& kv : ix->cached_batch) delete kv.second;
+    for (auto& kv : ix->cached_batch) delete kv.second->b;
     delete ix;
 }
 
@@ -162,10 +197,13 @@ int mtsv_index_to_device(mtsv_index* ix, int hip_device, uint32_t flags) {
         std::lock_guard<std::mutex> lk(ix->mu);
         auto it = ix->dev.find(hip_device);
         if (it == ix->dev.end() || it->second->flags != flags) {
-            auto cb = ix->cached_batch.find(hip_device);
-            if (cb != ix->cached_batch.end()) {
-                delete cb->second;
-                ix->cached_batch.erase(cb);
+            for (auto cb = ix->cached_batch.begin(); cb != ix->cached_batch.end();) {
+                if (cb->first.first == hip_device) {
+                    std::lock_guard<std::mutex> wl(cb->second->mu);  // no call may be running on it
+                    delete cb->second->b;
+                    cb = ix->cached_batch.erase(cb);
+                } else
+                    ++cb;
             }
             if (it != ix->dev.end()) ix->dev.erase(it);
             ix->dev[hip_device] = upload_index(ix->host, hip_device, flags);
@@ -221,32 +259,153 @@ int mtsv_batch_set_verify_mode(mtsv_batch* b, int mode) {
     return MTSV_OK;
 }
 
+int mtsv_set_default_verify_mode(int mode) {
+    if (mode != MTSV_VERIFY_REFERENCE && mode != MTSV_VERIFY_EDIT_FIRST) return fail_arg("bad verify mode");
+    mtsv::g_default_verify_mode = mode;
+    return MTSV_OK;
+}
+
 void mtsv_batch_free(mtsv_batch* b) { delete b; }
+
+// Three lanes of up to 1 Mi reads each (MTSV_WORKSPACE_READS overrides): ~2.7 KB of HBM per workspace read.
+uint64_t mtsv_bin_batch_workspace_reads(uint64_t n_reads) {
+    uint64_t cap = 3ull << 20;
+    if (const char* e = getenv("MTSV_WORKSPACE_READS")) cap = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
+    return std::min<uint64_t>(std::max<uint64_t>(n_reads, 1024), cap);
+}
+
+// One host batch (or a contiguous part of one) on one device, through the workspace kept for (device, slot).
+static void bin_batch_on(mtsv_index* ix, int hip_device, int slot, const uint8_t* bases, const uint64_t* read_off, uint64_t n_reads,
+                         uint64_t read_base, const mtsv_params& params, mtsv_hit** hits, uint64_t* n_hits) {
+    if (hip_device < 0) throw std::runtime_error("arg: hip_device must name a GPU: this library has no CPU path");
+    uint32_t flags = MTSV_DEV_DEFAULT;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        if (ix->dev.count(hip_device)) flags = ix->dev[hip_device]->flags;
+    }
+    if (int rc = mtsv_index_to_device(ix, hip_device, flags); rc != MTSV_OK) throw std::runtime_error(g_err);
+    mtsv_cached_workspace* ws;
+    DeviceIndex* di;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        auto& slot_ws = ix->cached_batch[{hip_device, slot}];
+        if (!slot_ws) slot_ws = std::make_unique<mtsv_cached_workspace>();
+        ws = slot_ws.get();
+        di = device_index(ix, hip_device);
+    }
+    std::lock_guard<std::mutex> wl(ws->mu);
+    // Workspace for slices of a bounded number of reads: larger host batches stream through it (run_host),
+    // which bounds the workspace (~2.7 KB of HBM per read) and overlaps the copies with compute.
+    const uint64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
+    const uint64_t slice_reads = mtsv_bin_batch_workspace_reads(n_reads);
+    const uint64_t slice_bases = n_reads > slice_reads
+                                     ? std::max<uint64_t>(1 << 16, (uint64_t)((double)nb / (double)n_reads * (double)slice_reads * 1.25) + 4096)
+                                     : std::max<uint64_t>(nb, 1 << 16);
+    if (!ws->b || ws->b->impl.max_reads < slice_reads || ws->b->impl.max_bases < slice_bases) {
+        delete ws->b;
+        ws->b = nullptr;
+        ws->b = new mtsv_batch(ix, di, slice_reads, slice_bases, 0);
+    }
+    ws->b->impl.run_host(bases, read_off, n_reads, params, read_base);
+    ws->b->impl.download(hits, n_hits);
+}
 
 int mtsv_bin_batch(mtsv_index* ix, int hip_device, const uint8_t* bases, const uint64_t* read_off, uint64_t n_reads,
                    const mtsv_params* params, mtsv_hit** hits, uint64_t* n_hits) {
     if (!ix || !read_off || !params || !hits || !n_hits) return fail_arg("null argument");
     if (hip_device < 0) return fail_arg("hip_device must name a GPU: this library has no CPU path");
-    int rc = mtsv_index_to_device(ix, hip_device, ix->dev.count(hip_device) ? ix->dev[hip_device]->flags : MTSV_DEV_DEFAULT);
-    if (rc != MTSV_OK) return rc;
-    GUARD({
-        std::lock_guard<std::mutex> lk(ix->mu);
-        // Workspace for slices of <= 1 Mi reads: larger host batches stream through it (run_host),
-        // which bounds the workspace (~2.7 KB of HBM per read) and overlaps the copy with compute.
-        const uint64_t nb = n_reads ? read_off[n_reads] - read_off[0] : 0;
-        const uint64_t slice_reads = std::min<uint64_t>(std::max<uint64_t>(n_reads, 1024), 1ull << 20);
-        const uint64_t slice_bases = n_reads > slice_reads
-                                         ? std::max<uint64_t>(1 << 16, (uint64_t)((double)nb / (double)n_reads * (double)slice_reads * 1.25) + 4096)
-                                         : std::max<uint64_t>(nb, 1 << 16);
-        mtsv_batch*& cb = ix->cached_batch[hip_device];
-        if (!cb || cb->impl.max_reads < slice_reads || cb->impl.max_bases < slice_bases) {
-            delete cb;
-            cb = nullptr;
-            cb = new mtsv_batch(ix, device_index(ix, hip_device), slice_reads, slice_bases, 0);
+    GUARD(bin_batch_on(ix, hip_device, 0, bases, read_off, n_reads, 0, *params, hits, n_hits))
+}
+
+
+// Mode A of SURVEY 8(e): index replicated, reads in contiguous blocks, host concat.
+int mtsv_bin_batch_multi(mtsv_index* ix, const int* devices, int n_devices, const uint8_t* bases, const uint64_t* read_off,
+                         uint64_t n_reads, const mtsv_params* params, mtsv_hit** hits, uint64_t* n_hits) {
+    if (!ix || !devices || n_devices < 1 || !read_off || !params || !hits || !n_hits) return fail_arg("null argument");
+    std::vector<mtsv_hit*> parts(n_devices, nullptr);
+    std::vector<uint64_t> cnt(n_devices, 0);
+    try {
+        fork_join(n_devices, [&](int k) {
+            const uint64_t a = n_reads * (uint64_t)k / n_devices, b = n_reads * (uint64_t)(k + 1) / n_devices;
+            bin_batch_on(ix, devices[k], slot_of(devices, k), bases, read_off + a, b - a, a, *params, &parts[k], &cnt[k]);
+        });
+        if (n_devices == 1) {
+            *hits = parts[0];
+            *n_hits = cnt[0];
+            return MTSV_OK;
         }
-        cb->impl.run_host(bases, read_off, n_reads, *params);
-        cb->impl.download(hits, n_hits);
-    })
+        uint64_t total = 0, cap = 0;
+        for (auto c : cnt) total += c;
+        mtsv_hit* out = pinned_hits_alloc(total, &cap);
+        std::vector<uint64_t> at(n_devices + 1, 0);
+        for (int k = 0; k < n_devices; k++) at[k + 1] = at[k] + cnt[k];
+        fork_join(n_devices, [&](int k) {
+            if (cnt[k]) memcpy(out + at[k], parts[k], cnt[k] * sizeof(mtsv_hit));
+        });
+        release_parts(parts);
+        *hits = out;
+        *n_hits = total;
+        return MTSV_OK;
+    } catch (const std::exception& e) {
+        release_parts(parts);
+        return fail(e);
+    }
+}
+
+// Mode B of SURVEY 8(e): one chunk of the database per entry, every chunk sees every read, the hit lists are
+// merged per read (mtsv-collapse then keeps the smallest edit per (read, TaxId): collapse.rs:597-602 -- and so
+// does mtsv_format_results on the merged list).
+int mtsv_bin_batch_chunks(mtsv_index* const* chunks, const int* devices, int n_chunks, const uint8_t* bases,
+                          const uint64_t* read_off, uint64_t n_reads, const mtsv_params* params, mtsv_hit** hits, uint64_t* n_hits) {
+    if (!chunks || !devices || n_chunks < 1 || !read_off || !params || !hits || !n_hits) return fail_arg("null argument");
+    for (int k = 0; k < n_chunks; k++)
+        if (!chunks[k]) return fail_arg("null chunk index");
+    std::vector<mtsv_hit*> parts(n_chunks, nullptr);
+    std::vector<uint64_t> cnt(n_chunks, 0);
+    try {
+        fork_join(n_chunks, [&](int k) {
+            // distinct index handles own distinct workspaces: slot 0 each
+            bin_batch_on(chunks[k], devices[k], 0, bases, read_off, n_reads, 0, *params, &parts[k], &cnt[k]);
+        });
+        if (n_chunks == 1) {
+            *hits = parts[0];
+            *n_hits = cnt[0];
+            return MTSV_OK;
+        }
+        uint64_t total = 0, cap = 0;
+        for (auto c : cnt) total += c;
+        mtsv_hit* out = pinned_hits_alloc(total, &cap);
+        // k-way merge by read, chunk order within a read; read ranges in parallel
+        const int T = (int)std::min<uint64_t>(8, std::max<uint64_t>(1, total >> 16));
+        auto lower = [&](int k, uint64_t r) {  // first hit of part k with read >= r
+            return (uint64_t)(std::lower_bound(parts[k], parts[k] + cnt[k], r, [](const mtsv_hit& h, uint64_t v) { return h.read < v; }) - parts[k]);
+        };
+        fork_join(T, [&](int t) {
+            const uint64_t r0 = n_reads * (uint64_t)t / T, r1 = n_reads * (uint64_t)(t + 1) / T;
+            std::vector<uint64_t> pos(n_chunks), end(n_chunks);
+            uint64_t o = 0;
+            for (int k = 0; k < n_chunks; k++) {
+                pos[k] = lower(k, r0);
+                end[k] = t + 1 == T ? cnt[k] : lower(k, r1);
+                o += pos[k];
+            }
+            for (;;) {
+                uint64_t r = ~0ull;
+                for (int k = 0; k < n_chunks; k++)
+                    if (pos[k] < end[k]) r = std::min(r, parts[k][pos[k]].read);
+                if (r == ~0ull) break;
+                for (int k = 0; k < n_chunks; k++)
+                    while (pos[k] < end[k] && parts[k][pos[k]].read == r) out[o++] = parts[k][pos[k]++];
+            }
+        });
+        release_parts(parts);
+        *hits = out;
+        *n_hits = total;
+        return MTSV_OK;
+    } catch (const std::exception& e) {
+        release_parts(parts);
+        return fail(e);
+    }
 }
 
 void mtsv_hits_free(mtsv_hit* hits) {

@@ -45,9 +45,14 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
 }  // namespace mtsv
 
 // the opaque C handle
+struct mtsv_cached_workspace {  // workspace kept between mtsv_bin_batch* calls; mu held while a call runs on it
+    std::mutex mu;
+    struct mtsv_batch* b = nullptr;
+};
 struct mtsv_index {
     mtsv::HostIndex host;
-    std::mutex mu;
+    std::mutex mu;  // guards the two maps (never held while a batch runs)
     std::map<int, std::unique_ptr<mtsv::DeviceIndex>> dev;
-    std::map<int, struct mtsv_batch*> cached_batch;  // workspace reused by mtsv_bin_batch
+    // (device, slot): slot > 0 when one call lists a device more than once (mtsv_bin_batch_multi)
+    std::map<std::pair<int, int>, std::unique_ptr<mtsv_cached_workspace>> cached_batch;
 };

@@ -1451,6 +1451,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
     uint32_t t = 0, steps = 0;
     uint32_t checks = 0;  // next decision point (low 16 bits, saturated) and the scheduled second one (high 16 bits)
     uint32_t verified = 0, wbytes = 0;  // per group: far below 2^32 in one launch
+    unsigned long long swept = 0;       // columns this group's sweeps advanced (a column = R rows of both halves)
 #pragma unroll
     for (int r = 0; r < R; r++) {
         qc2[r] = 0x000c000cu;  // code 6 << 1 in both halves: matches nothing
@@ -1804,6 +1805,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         }
         if (__builtin_expect(phase == PH_SWEEP && finish, 0)) {
             int bm[2];
+            swept += t;
 
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) bm[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;
@@ -1834,14 +1836,16 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         wave_lds_handoff();
         for (uint32_t i = gl; i < pend; i += GS) a.pass_list[base + i] = pend_buf[i];
     }
-    unsigned long long v64 = gl == 0 ? verified : 0, w64 = gl == 0 ? wbytes : 0;
+    unsigned long long v64 = gl == 0 ? verified : 0, w64 = gl == 0 ? wbytes : 0, s64 = gl == 0 ? swept : 0;
     for (int d = 32; d > 0; d >>= 1) {
         v64 += __shfl_down(v64, d);
         w64 += __shfl_down(w64, d);
+        s64 += __shfl_down(s64, d);
     }
     if (lane == 0 && v64) {
         atomicAdd(a.n_verified, v64);
         atomicAdd(a.window_bytes, w64);
+        if (s64) atomicAdd(a.sw_columns, s64 * R);  // cell pairs swept (one packed 7-instruction recurrence each)
     }
 }
 

@@ -34,6 +34,7 @@ struct EvalArgs {
     uint4* out;                   // out[candidate] = (tax_id, gi, offset, edit) when it passed
     unsigned long long* n_verified;
     unsigned long long* window_bytes;
+    unsigned long long* sw_columns = nullptr;  // k_sw_pairs: packed DP cell pairs swept (group columns x rows per lane)
     // reference order, reads <= 253 bases: k_sw_pairs appends candidates that pass the prefilter to
     // pass_list; k_edit_myers (list mode) verifies them and appends the successors of those that fail
     // the edit distance to next_list, the worklist of the next round

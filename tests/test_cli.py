@@ -124,6 +124,69 @@ def test_chunk_mode_binner_then_collapse_equals_oracle_per_chunk(tmp_path):
         assert a.read_text() == b.read_text() and len(a.read_text()) > 200
 
 
+@pytest.mark.gpu
+def test_cli_devices_list_gives_the_single_device_output(tmp_path):
+    """Mode A of SURVEY 8(e) in the product: --devices 0,0 = two workers with a workspace each on one GPU
+    pulling the read batches; lines and their order equal the single-device run (README.md:69-73 workflow)."""
+    import helpers
+    entries, gene, unit = helpers.tricky_db(seed=7)
+    reads = [r for r in helpers.tricky_reads(entries, gene, unit, seed=33, n_each=40, lengths=(150, 100)) if len(r) > 0]
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "w", encoding="latin-1") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@q{i}\n{r.decode('latin-1')}\n+\n{'I' * len(r)}\n")
+    idx = tmp_path / "db.idx"
+    M.MGIndex.build(entries, threads=2).write(str(idx))
+    one, two, three = tmp_path / "one.txt", tmp_path / "two.txt", tmp_path / "three.txt"
+    assert run("--fastq", str(fq), "-i", str(idx), "-m", str(one), "--batch-reads", "37").returncode == 0
+    r = run("--fastq", str(fq), "-i", str(idx), "-m", str(two), "--batch-reads", "37", "--devices", "0,0")
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert run("--fastq", str(fq), "-i", str(idx), "-m", str(three), "--batch-reads", "11", "--devices", "0,0,0", "--output-format", "long").returncode == 0
+    assert one.read_text() == two.read_text() and len(one.read_text()) > 1000
+    ref_long = tmp_path / "long.txt"
+    assert run("--fastq", str(fq), "-i", str(idx), "-m", str(ref_long), "--output-format", "long").returncode == 0
+    assert ref_long.read_text() == three.read_text()
+    # the reference-order verification gives the same file (the command line defaults to edit-first)
+    env = dict(os.environ, MTSV_VERIFY="reference")
+    ref = tmp_path / "ref.txt"
+    assert subprocess.run([BIN, "--fastq", str(fq), "-i", str(idx), "-m", str(ref)], env=env, capture_output=True).returncode == 0
+    assert ref.read_text() == one.read_text()
+    assert run("--fastq", str(fq), "-i", str(idx), "-m", str(ref), "--devices", "0,x").returncode == 1
+    assert run("--fastq", str(fq), "-i", str(idx), "-m", str(ref), "--batch-reads", "0").returncode == 1
+    assert run("--fastq", str(fq), "-i", str(idx), "-m", str(ref), "--batch-reads", "many").returncode == 1
+
+
+@pytest.mark.gpu
+def test_cli_chunk_list_merges_like_collapse(tmp_path):
+    """Mode B of SURVEY 8(e) in the product: --index a,b,c (the chunks of one database) writes ONE results file
+    whose collapse equals the collapse of the three per-chunk result files (README.md:189, collapse.rs:597-625)."""
+    import helpers
+    entries, gene, unit = helpers.tricky_db(seed=7)
+    reads = [r for r in helpers.tricky_reads(entries, gene, unit, seed=21, n_each=25) if 0 < len(r) <= 253]
+    fq = tmp_path / "reads.fastq"
+    with open(fq, "w", encoding="latin-1") as f:
+        for i, r in enumerate(reads):
+            f.write(f"@q{i}\n{r.decode('latin-1')}\n+\n{'I' * len(r)}\n")
+    collapse = os.path.join(ROOT, "mtsv_tools_amd", "bin", "mtsv-collapse")
+    idxs, per_chunk = [], []
+    for c in range(3):
+        idx = tmp_path / f"chunk{c}.idx"
+        M.MGIndex.build(entries[c::3], threads=2).write(str(idx))
+        idxs.append(str(idx))
+        out = tmp_path / f"gpu{c}.txt"
+        assert run("--fastq", str(fq), "-i", str(idx), "-m", str(out)).returncode == 0
+        per_chunk.append(str(out))
+    merged = tmp_path / "merged.txt"
+    r = run("--fastq", str(fq), "-i", ",".join(idxs), "-m", str(merged), "--devices", "0,0,0", "--batch-reads", "64")
+    assert r.returncode == 0, r.stdout + r.stderr
+    a, b = tmp_path / "a.txt", tmp_path / "b.txt"
+    assert subprocess.run([collapse, "-o", str(a), *per_chunk]).returncode == 0
+    assert subprocess.run([collapse, "-o", str(b), str(merged)]).returncode == 0
+    assert a.read_text() == b.read_text() and len(a.read_text()) > 200
+    # the merged file already holds one line per read with the smallest edit per TaxId: collapse changes nothing but order
+    assert sorted(merged.read_text().splitlines()) == sorted(b.read_text().splitlines())
+
+
 def test_mtsv_build_cli_writes_the_reference_layout(tmp_path):
     """bin/mtsv-build (host suffix sort here: --device -1): same bytes as the library builder and the
     oracle's MGIndex::new restatement; header grammar and mapping-file handling of src/io.rs"""

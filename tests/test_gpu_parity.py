@@ -338,6 +338,59 @@ def test_stray_long_reads_do_not_fail_the_batch(tricky):
     b.close()
 
 
+def test_bin_batch_multi_shards_reads_over_device_entries(tricky, medium):
+    """mtsv_bin_batch_multi (Mode A): contiguous read blocks over the listed devices, one workspace per entry;
+    listing GPU 0 twice / three times gives the single-device hits, read indices included."""
+    ix, orc, reads = tricky
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want = ix.bin_batch(bases, off, device=0)
+    for devs in ([0], [0, 0], [0, 0, 0]):
+        assert_same_hits(M.bin_batch_multi(ix, devs, bases, off), want)
+    mix, mbases, moff = medium
+    mix.to_device(0)
+    mwant = mix.bin_batch(mbases, moff, device=0)
+    assert_same_hits(M.bin_batch_multi(mix, [0, 0], mbases, moff), mwant)
+    assert len(M.bin_batch_multi(ix, [0, 0], np.zeros(0, np.uint8), np.zeros(1, np.uint64))) == 0
+    with pytest.raises(M.MtsvError):
+        M.bin_batch_multi(ix, [0, 99], bases, off)  # no such device: the whole call fails, nothing leaks
+
+
+def test_bin_batch_chunks_merges_hits_per_read(tmp_path):
+    """mtsv_bin_batch_chunks (Mode B): three chunks of the database, every chunk sees every read; the merged
+    list equals the oracle's per-chunk hits merged per read in chunk order, and its result lines equal the
+    smallest edit per TaxId over the chunks (collapse.rs:597-602)."""
+    entries, gene, unit = helpers.tricky_db(seed=7)
+    reads = helpers.tricky_reads(entries, gene, unit, seed=5, n_each=30)
+    bases, off = helpers.reads_to_batch(reads)
+    chunks, per = [], []
+    for c in range(3):
+        ix = M.MGIndex.build(entries[c::3], threads=2)
+        p = str(tmp_path / f"c{c}.idx")
+        ix.write(p)
+        chunks.append(ix)
+        per.append(O.Index.read(p).bin_batch(bases, off, threads=8)[0])
+    allh = np.concatenate(per)
+    order = np.lexsort((np.concatenate([np.full(len(h), c) for c, h in enumerate(per)]), allh["read"]))  # stable: read, chunk
+    want = allh[order]
+    got = M.bin_batch_chunks(chunks, [0, 0, 0], bases, off)
+    assert_same_hits(got, want)
+    ids = [f"r{i}" for i in range(len(reads))]
+    lines = M.format_results(got, ids, False).splitlines()
+    best = {}
+    for h in want:
+        k = (int(h["read"]), int(h["tax_id"]))
+        best[k] = min(best.get(k, 1 << 30), int(h["edit"]))
+    assert len(lines) == len({k[0] for k in best})
+    for line in lines:
+        rid, rest = line.split(":")
+        for tok in rest.split(","):
+            t, e = tok.split("=")
+            assert best[(int(rid[1:]), int(t))] == int(e)
+    for ix in chunks:
+        ix.close()
+
+
 def test_repeated_calls_with_changing_batch_shapes(small_db):
     """mtsv_bin_batch reuses / regrows its cached workspace: sizes going up and down, different read
     lengths and parameter sets back to back, two devices-structure flavours, same answers"""
