@@ -3,15 +3,19 @@
 // smallest edit per TaxId (mode taxid) or per (TaxId, GI) with the smallest offset as tie-break
 // (mode taxid-gi), write one line per read id in ascending read-id order, optional per-TaxId
 // report (collapse.rs:717-753).  Host-side text processing: SURVEY 8(f) rank 2, needed to score
-// BASELINE config 5 (one index chunk per GPU, reads broadcast).  Inputs are sorted in memory.
+// BASELINE config 5 (one index chunk per GPU, reads broadcast).  Inputs are sorted externally in runs of
+// 128 MiB (collapse.rs:427-475,665), so result files larger than memory collapse too.
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <memory>
 #include <string>
 #include <vector>
+
+#include <unistd.h>
 
 namespace {
 
@@ -110,28 +114,102 @@ int main(int argc, char** argv) {
     }
     const bool by_gi = mode == "taxid-gi";
 
-    // (read id, file index, hits text); sorted by (read id, file index) like the heap of collapse.rs:553-566
-    struct Line {
+    // External sort like collapse.rs:427-475,665: every input is cut into runs of at most `chunk_bytes` of
+    // lines (128 MiB there and here; MTSV_COLLAPSE_CHUNK_BYTES for tests), each run is sorted by read id and
+    // -- unless it is the last, still in memory -- written to a temporary directory; then one k-way merge over
+    // all runs of all files (the reference merges per file first, then across files: same stream) feeds the
+    // grouping loop of collapse.rs:543-654.  Memory: one run per input file at a time, one line per run later.
+    uint64_t chunk_bytes = 128ull << 20;
+    if (const char* e = getenv("MTSV_COLLAPSE_CHUNK_BYTES")) chunk_bytes = std::max<uint64_t>(1, strtoull(e, nullptr, 10));
+    struct Rec {
         std::string id, hits;
-        size_t file;
     };
-    std::vector<Line> lines;
+    struct Run {
+        std::vector<Rec> mem;  // in-memory run (sorted), or empty when spilled
+        size_t at = 0;
+        std::string path;
+        std::unique_ptr<std::ifstream> in;
+        Rec cur;
+        bool next() {  // advance to the next record; false at the end
+            if (in) {
+                std::string l;
+                if (!std::getline(*in, l)) return false;
+                const size_t c = l.rfind(':');
+                cur.id = l.substr(0, c);
+                cur.hits = l.substr(c + 1);
+                return true;
+            }
+            if (at >= mem.size()) return false;
+            cur = std::move(mem[at++]);
+            return true;
+        }
+    };
+    std::vector<std::unique_ptr<Run>> runs;
+    std::string tmp_dir;
+    auto spill = [&](std::vector<Rec>& recs) {
+        if (tmp_dir.empty()) {
+            const char* base = getenv("TMPDIR");
+            std::string t = std::string(base && *base ? base : "/tmp") + "/mtsv-collapse-XXXXXX";
+            std::vector<char> buf(t.begin(), t.end());
+            buf.push_back('\0');
+            if (!mkdtemp(buf.data())) die("cannot create a temporary directory under " + t);
+            tmp_dir = buf.data();
+        }
+        auto r = std::make_unique<Run>();
+        r->path = tmp_dir + "/run-" + std::to_string(runs.size()) + ".txt";
+        FILE* f = fopen(r->path.c_str(), "wb");
+        if (!f) die("cannot write " + r->path);
+        for (auto& rec : recs) {
+            if (fwrite(rec.id.data(), 1, rec.id.size(), f) != rec.id.size() || fputc(':', f) == EOF ||
+                fwrite(rec.hits.data(), 1, rec.hits.size(), f) != rec.hits.size() || fputc('\n', f) == EOF)
+                die("write error in " + r->path);
+        }
+        if (fclose(f) != 0) die("write error in " + r->path);
+        recs.clear();
+        recs.shrink_to_fit();
+        runs.push_back(std::move(r));
+    };
+    auto by_id = [](const Rec& a, const Rec& b) { return a.id < b.id; };
     for (size_t f = 0; f < files.size(); f++) {
         std::ifstream in(files[f], std::ios::binary);
         if (!in) die("cannot open " + files[f]);
+        std::vector<Rec> recs;
+        uint64_t bytes = 0;
         std::string l;
         while (std::getline(in, l)) {
             while (!l.empty() && (l.back() == '\r' || l.back() == '\n')) l.pop_back();
             if (l.find_first_not_of(" \t") == std::string::npos) continue;
             size_t c = l.rfind(':');  // rsplitn(2, ':'), collapse.rs:180-191
             if (c == std::string::npos || c == 0) die("InvalidHeader(" + l + ")");
-            lines.push_back(Line{l.substr(0, c), l.substr(c + 1), f});
+            bytes += l.size() + 1;
+            recs.push_back(Rec{l.substr(0, c), l.substr(c + 1)});
+            if (bytes >= chunk_bytes) {
+                std::stable_sort(recs.begin(), recs.end(), by_id);
+                spill(recs);
+                bytes = 0;
+            }
+        }
+        if (!recs.empty()) {
+            std::stable_sort(recs.begin(), recs.end(), by_id);
+            auto r = std::make_unique<Run>();
+            r->mem = std::move(recs);
+            runs.push_back(std::move(r));
         }
     }
-    std::stable_sort(lines.begin(), lines.end(), [](const Line& a, const Line& b) {
-        if (a.id != b.id) return a.id < b.id;
-        return a.file < b.file;
-    });
+    for (auto& r : runs)
+        if (!r->path.empty()) {
+            r->in = std::make_unique<std::ifstream>(r->path, std::ios::binary);
+            if (!*r->in) die("cannot reopen " + r->path);
+        }
+    // min-heap over the runs' current records: (read id, run index) like collapse.rs:553-566
+    auto later = [&](size_t a, size_t b) {
+        const int c = runs[a]->cur.id.compare(runs[b]->cur.id);
+        return c != 0 ? c > 0 : a > b;
+    };
+    std::vector<size_t> heap;
+    for (size_t k = 0; k < runs.size(); k++)
+        if (runs[k]->next()) heap.push_back(k);
+    std::make_heap(heap.begin(), heap.end(), later);
 
     FILE* out = fopen(out_path.c_str(), "wb");
     if (!out) {
@@ -141,15 +219,18 @@ int main(int argc, char** argv) {
     std::map<uint32_t, Stats> stats;
     uint64_t total_reads = 0;
     int offset_format = -1;  // unknown / 0 / 1
-    size_t i = 0;
-    std::string text;
+    std::string text, cur_id;
     char num[96];
-    while (i < lines.size()) {
-        size_t j = i;
+    while (!heap.empty()) {
+        cur_id = runs[heap.front()]->cur.id;
         std::map<uint32_t, uint32_t> tax_hits;                                      // taxid -> min edit
         std::map<std::pair<uint32_t, uint32_t>, std::pair<uint32_t, uint64_t>> gi_hits;  // (taxid, gi) -> (edit, offset)
-        for (; j < lines.size() && lines[j].id == lines[i].id; j++) {
-            const std::string& hs = lines[j].hits;
+        while (!heap.empty() && runs[heap.front()]->cur.id == cur_id) {
+            std::pop_heap(heap.begin(), heap.end(), later);
+            const size_t k = heap.back();
+            const std::string hs = std::move(runs[k]->cur.hits);
+            if (runs[k]->next()) std::push_heap(heap.begin(), heap.end(), later);
+            else heap.pop_back();
             size_t p = 0;
             while (!hs.empty()) {
                 size_t c = hs.find(',', p);
@@ -213,9 +294,14 @@ int main(int argc, char** argv) {
                 any = true;
             }
         }
-        if (any) fprintf(out, "%s:%s\n", lines[i].id.c_str(), text.c_str());
-        i = j;
+        if (any) fprintf(out, "%s:%s\n", cur_id.c_str(), text.c_str());
     }
+    for (auto& r : runs)
+        if (!r->path.empty()) {
+            r->in.reset();
+            remove(r->path.c_str());
+        }
+    if (!tmp_dir.empty()) rmdir(tmp_dir.c_str());
     if (fclose(out) != 0) die("write error");
     if (!report.empty()) {
         FILE* r = fopen(report.c_str(), "wb");

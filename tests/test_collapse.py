@@ -45,3 +45,32 @@ def test_errors_and_report(tmp_path):
     rows = [l.split("\t") for l in rep.read_text().splitlines()]
     assert rows[0][0] == "taxid" and rows[1][:2] == ["1", "1"] and rows[1][3] == "1" and rows[1][5] == "1"
     assert rows[2][0] == "2" and rows[2][7] == "1" and rows[2][5] == "1"
+
+
+def test_external_sort_runs_give_the_in_memory_result(tmp_path):
+    """collapse.rs:427-475,665: inputs are sorted in bounded runs spilled to a temporary directory and merged;
+    tiny runs (64 bytes instead of 128 MiB) must not change a byte of the output, and leave no files behind."""
+    import random
+    rng = random.Random(5)
+    files = []
+    for f in range(4):
+        lines = []
+        for r in rng.sample(range(600), 400):
+            hits = ",".join(f"{rng.randrange(1, 40)}-{rng.randrange(1, 5)}-{rng.randrange(0, 9000)}={rng.randrange(0, 20)}"
+                            for _ in range(rng.randrange(1, 6)))
+            lines.append(f"read_{r}:x:{hits}" if r % 7 == 0 else f"read_{r}:{hits}")  # ids may hold ':' (rsplit)
+        files.append("\n".join(lines) + "\n")
+    tmp = tmp_path / "tmpdir"
+    tmp.mkdir()
+    for mode in ("taxid", "taxid-gi"):
+        r0, want = collapse(tmp_path, files, "--mode", mode)
+        assert r0.returncode == 0 and want.count("\n") == len({l.rsplit(":", 1)[0] for f in files for l in f.splitlines()})
+        paths = [str(tmp_path / f"in{i}.txt") for i in range(4)]
+        out = tmp_path / "spilled.txt"
+        env = dict(os.environ, MTSV_COLLAPSE_CHUNK_BYTES="64", TMPDIR=str(tmp))
+        r1 = subprocess.run([BIN, "-o", str(out), "--mode", mode, *paths], capture_output=True, text=True, env=env)
+        assert r1.returncode == 0, r1.stderr
+        assert out.read_text() == want
+        assert os.listdir(tmp) == []
+    ids = [l.rsplit(":", 1)[0] for l in want.splitlines()]
+    assert ids == sorted(ids)
