@@ -645,6 +645,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
         uint64_t begin = 0, end = 0;
         uint32_t max_len = 0;
         bool ready = false, done = false;
+        size_t buf = 0;
         Batch* lane = nullptr;
         uint64_t hit_off = 0, hit_cnt = 0;
     };
@@ -652,7 +653,11 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     std::condition_variable cv;
     std::vector<Slice> slices;
     uint64_t cut_at = 0;       // reads already cut into slices
-    uint64_t released = 0;     // slices [0, released) have left their ring buffers
+    uint64_t next_grant = 0;   // next slice to be given an input buffer
+    std::vector<size_t> free_bufs;
+    for (size_t b = 0; b < NB; b++) free_bufs.push_back(b);
+    uint64_t ramp_floor = 192 << 10;
+    if (const char* e = getenv("MTSV_RAMP_FLOOR")) ramp_floor = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));
     uint64_t next_take = 0;    // next slice a lane takes
     uint64_t next_commit = 0;  // next slice whose hits go to the host
     bool abort = false;
@@ -680,6 +685,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
             hipStream_t cs = copy_streams[tid];
             for (;;) {
                 uint64_t k, s, e;
+                size_t bi;
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     if (abort || cut_at >= n) return;
@@ -690,9 +696,9 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     // copying) and taper off towards the end of the batch (the lanes finish together).
                     uint64_t want = slice_reads;
                     if (n > 2 * slice_reads) {
-                        const uint64_t lanes = ls.size(), floor_reads = std::min<uint64_t>(slice_reads, 96 << 10);
+                        const uint64_t lanes = ls.size(), floor_reads = std::min<uint64_t>(slice_reads, ramp_floor);
                         const uint64_t up = floor_reads + s / lanes;                  // grows with the reads already cut
-                        const uint64_t down = std::max(floor_reads, (n - s) / (2 * lanes));  // shrinks with the reads left
+                        const uint64_t down = std::max(floor_reads, (n - s) / (lanes + 1));  // shrinks with the reads left
                         want = std::min(slice_reads, std::min(up, down));
                     }
                     e = std::min(n, s + want);
@@ -711,10 +717,17 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     slices[k].begin = s;
                     slices[k].end = e;
                     cut_at = e;
-                    cv.wait(lk, [&] { return abort || k < released + NB; });  // ring buffer k % NB is free
+                    // input buffers are granted in slice order (a later slice must not starve an earlier one the
+                    // lanes are waiting for) and come back in any order
+                    cv.wait(lk, [&] { return abort || (k == next_grant && !free_bufs.empty()); });
                     if (abort) return;
+                    slices[k].buf = free_bufs.back();
+                    free_bufs.pop_back();
+                    next_grant++;
+                    bi = slices[k].buf;
                 }
-                RingBuf& rb = ring[k % NB];
+                cv.notify_all();
+                RingBuf& rb = ring[bi];
                 const uint64_t cnt = e - s, first = read_off[s], nb = read_off[e] - first;
                 uint32_t ml = 0;
                 for (uint64_t i = 0; i <= cnt; i++) {
@@ -773,7 +786,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     sl = slices[k];
                 }
                 cv.notify_all();
-                const RingBuf& rb = ring[k % NB];
+                const RingBuf& rb = ring[sl.buf];
                 const uint64_t before = lane->n_hits_total;
                 const double t0 = now_s();
                 // base normalisation (binner.rs:88-100) in place, on the lane's own stream: a kernel on the copy
@@ -788,8 +801,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     slices[k].hit_cnt = lane->n_hits_total - before;
                     slices[k].done = true;
                     max_len = std::max(max_len, sl.max_len);
-                    // ring buffers leave in order: slice k's buffer is reusable once every earlier one is
-                    while (released < slices.size() && slices[released].done) released++;
+                    free_bufs.push_back(sl.buf);
                     commit_ready();
                 }
                 cv.notify_all();

@@ -199,8 +199,11 @@ int mtsv_index_to_device(mtsv_index* ix, int hip_device, uint32_t flags) {
         if (it == ix->dev.end() || it->second->flags != flags) {
             for (auto cb = ix->cached_batch.begin(); cb != ix->cached_batch.end();) {
                 if (cb->first.first == hip_device) {
-                    std::lock_guard<std::mutex> wl(cb->second->mu);  // no call may be running on it
-                    delete cb->second->b;
+                    {
+                        std::lock_guard<std::mutex> wl(cb->second->mu);  // no call may be running on it
+                        delete cb->second->b;
+                        cb->second->b = nullptr;
+                    }
                     cb = ix->cached_batch.erase(cb);
                 } else
                     ++cb;

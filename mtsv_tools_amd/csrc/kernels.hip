@@ -694,6 +694,7 @@ __global__ __launch_bounds__(256) void k_coalesce_heavy(DevIndexView ix, HeavyAr
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
         const uint32_t rs = heavy_list[h];
         const uint32_t nh = a.strand_off[rs + 1] - a.strand_off[rs];
+        if (nh <= (uint32_t)kWave) continue;  // k_coalesce_mid's
         if (nh <= kHeavyKeys) {
             coalesce_big<true>(ix, a, rs, KeyMem<true>{lk}, &sh_nc);
         } else {
@@ -704,235 +705,267 @@ __global__ __launch_bounds__(256) void k_coalesce_heavy(DevIndexView ix, HeavyAr
 }
 
 
-__global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, const uint32_t* __restrict__ read_off, uint32_t r0,
-                                                  uint32_t n_strands, double edit_rate, double min_seed,
-                                                  int64_t max_candidates, const uint32_t* __restrict__ strand_off,
-                                                  const uint32_t* __restrict__ strand_nseeds,
-                                                  const uint32_t* __restrict__ hit_ref,
-                                                  const uint32_t* __restrict__ hit_q, uint64_t* __restrict__ hit_key,
-                                                  uint64_t* __restrict__ cand_tmp, uint4* __restrict__ cand,
-                                                  uint32_t* __restrict__ cand_next, uint32_t* __restrict__ cand_rs,
-                                                  uint32_t* __restrict__ cand_status,
-                                                  uint32_t* __restrict__ strand_ncand,
-                                                  uint32_t* __restrict__ worklist, uint32_t* __restrict__ wl_count,
-                                                  uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ heavy_count,
-                                                  unsigned long long* __restrict__ n_cand_total) {
+// Strands with at most 16 seed hits, four per wavefront (one 16-lane group each); longer ones go to the list
+// k_coalesce_mid (17..64 hits, a wavefront each) and k_coalesce_heavy (more) work off.
+struct CoalesceArgs {
+    const uint32_t* read_off;
+    uint32_t r0, n_strands;
+    double edit_rate, min_seed;
+    uint32_t maxc;
+    const uint32_t* strand_off;
+    const uint32_t* strand_nseeds;
+    const uint32_t* hit_ref;
+    const uint32_t* hit_q;
+    uint4* cand;
+    uint32_t* cand_next;
+    uint32_t* cand_rs;
+    uint32_t* cand_status;
+    uint32_t* strand_ncand;
+    uint32_t* worklist;
+    uint32_t* wl_count;
+    uint32_t* heavy_list;
+    uint32_t* heavy_count;
+    unsigned long long* n_cand_total;
+};
+
+__global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs a) {
     __shared__ uint32_t pend_all[256 / kWave][kWave];
     uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
-    const uint32_t maxc = max_candidates < 0 ? 0xffffffffu
-                                             : (max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)max_candidates);
     const uint32_t lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
     uint32_t pend = 0;  // work items buffered in pend_buf (wave-uniform)
     unsigned long long cand_sum = 0;
-    for (uint32_t rs4 = wave * 4; rs4 < n_strands; rs4 += n_waves * 4) {
-      // ---- fast path: four strands at once, one per 16-lane group, when each has <= 16 seed hits ----
-      {
+    for (uint32_t rs4 = wave * 4; rs4 < a.n_strands; rs4 += n_waves * 4) {
         const uint32_t gl = lane & 15, gbase = lane & 48;
         const uint32_t grs = rs4 + (lane >> 4);
-        const bool gvalid = grs < n_strands;
-        const uint32_t go = gvalid ? strand_off[grs] : 0;
-        const uint32_t gnh = gvalid ? strand_off[grs + 1] - go : 0;
-        if (!__any(gnh > 16)) {
-            uint32_t maxnh = gnh;
-            maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 16));
-            maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 32));
-            maxnh = __builtin_amdgcn_readfirstlane(maxnh);
-            if (maxnh == 0) {
-                if (gvalid && gl == 0) strand_ncand[grs] = 0;
-                continue;
-            }
-            StrandGeom gg{0, 0, 1};
-            if (gvalid && gnh) gg = strand_geom(read_off, r0 + (grs >> 1), edit_rate, min_seed, strand_nseeds[grs]);
-            uint64_t key = gl < gnh ? ((uint64_t)hit_ref[go + gl] << 32) | hit_q[go + gl] : ~0ull;
-            for (uint32_t k = 2; k <= 16; k <<= 1)  // bitonic sort inside the 16-lane group
-                for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                    uint64_t other = __shfl_xor(key, j);
-                    bool up = (gl & k) == 0, lower = (gl & j) == 0;
-                    key = (lower == up) ? min(key, other) : max(key, other);
-                }
-            uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-            uint32_t b = 0, ws = 0, we = 0, btax = 0;
-            bool ok = false;
-            if (gl < gnh) {
-                b = min(find_bin(ix, site), ix.n_bins - 1);
-                DevBin bin = ix.bins[b];
-                btax = bin.tax_id;  // travels with the walk: no dependent reload of the candidate's bin
-                ok = candidate_window(site, q, bin, gg.L, gg.ED, &ws, &we);
-            }
-            Walk w{false, 0, 0, 0, 0};
-            uint32_t wtax = 0;
-            uint32_t gnc = 0, ms = 0, me = 0, mb = 0, mn = 0, mtax = 0;
-            for (uint32_t i = 0; i < maxnh; i++) {
-                const int src = (int)(gbase + i);
-                uint32_t wsi = (uint32_t)__shfl((int)ws, src), wei = (uint32_t)__shfl((int)we, src);
-                uint32_t bi = (uint32_t)__shfl((int)b, src), ti = (uint32_t)__shfl((int)btax, src);
-                bool oki = __shfl((int)ok, src) != 0;
-                if (i < gnh) {
-                    bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
-                    if (merge) {
-                        w.s = min(w.s, wsi);
-                        w.e = max(w.e, wei);
-                        w.n++;
-                    } else {
-                        if (w.have && w.n >= gg.min_seeds) {
-                            if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
-                            gnc++;
-                        }
-                        w.have = oki;
-                        w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
-                        wtax = ti;
-                    }
-                }
-            }
-            if (w.have && w.n >= gg.min_seeds) {
-                if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
-                gnc++;
-            }
-            uint32_t maxnc = gnc;
-            maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 16));
-            maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 32));
-            maxnc = __builtin_amdgcn_readfirstlane(maxnc);
-            const uint32_t tax = gl < gnc ? mtax : 0;
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < maxnc; j++) {
-                uint32_t nj = (uint32_t)__shfl((int)mn, (int)(gbase + j));
-                if (j < gnc) rank += (nj > mn) || (nj == mn && j < gl);
-            }
-            uint32_t nxt = 0xffffffffu;
-            bool first = gl < gnc;
-            for (uint32_t j = 0; j < maxnc; j++) {
-                uint32_t tj = (uint32_t)__shfl((int)tax, (int)(gbase + j)), rj = (uint32_t)__shfl((int)rank, (int)(gbase + j));
-                if (j < gnc) {
-                    if (tj == tax && rj > rank && rj < nxt) nxt = rj;
-                    if (tj == tax && rj < rank) first = false;
-                }
-            }
-            if (gl < gnc) {
-                cand[go + rank] = make_uint4(ms, me, mb, mn);
-                cand_next[go + rank] = nxt;
-                cand_rs[go + rank] = grs;
-                cand_status[go + rank] = 0;
-            }
-            if (gvalid && gl == 0) strand_ncand[grs] = gnc;
-            if (gl == 0) cand_sum += gnc;
-            {
-                bool emit = first && rank < maxc;
-                unsigned long long em = __ballot(emit);
-                uint32_t m = __popcll(em);
-                if (pend + m > kWave) {
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(wl_count, pend);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (lane < pend) worklist[base + lane] = pend_buf[lane];
-                    pend = 0;
-                }
-                if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = go + rank;
-                pend += m;
-            }
+        const bool gvalid = grs < a.n_strands;
+        const uint32_t go = gvalid ? a.strand_off[grs] : 0;
+        uint32_t gnh = gvalid ? a.strand_off[grs + 1] - go : 0;
+        const bool big = gnh > 16;
+        if (big) {  // not this kernel's: its group idles through this pass
+            if (gl == 0) a.heavy_list[atomicAdd(a.heavy_count, 1u)] = grs;
+            gnh = 0;
+        }
+        uint32_t maxnh = gnh;
+        maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 16));
+        maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 32));
+        maxnh = __builtin_amdgcn_readfirstlane(maxnh);
+        if (maxnh == 0) {
+            if (gvalid && gl == 0 && !big) a.strand_ncand[grs] = 0;
             continue;
         }
-      }
-      // ---- general path: one strand at a time over the whole wavefront ----
-      for (uint32_t rs = rs4; rs < min(rs4 + 4, n_strands); rs++) {
-        const uint32_t o = strand_off[rs];
-        const uint32_t nh = __builtin_amdgcn_readfirstlane(strand_off[rs + 1] - o);
-        if (nh == 0) {
-            if (lane == 0) strand_ncand[rs] = 0;
-            continue;
-        }
-        const StrandGeom g = strand_geom(read_off, r0 + (rs >> 1), edit_rate, min_seed, strand_nseeds[rs]);
-        uint32_t nc = 0;
-        if (nh <= kWave) {
-            // ---- registers only ----
-            uint64_t key = lane < nh ? ((uint64_t)hit_ref[o + lane] << 32) | hit_q[o + lane] : ~0ull;
-            key = wave_bitonic_sort(key);  // seed_hits.sort(): (reference_offset, query_offset), index.rs:443
-            uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-            uint32_t b = 0, ws = 0, we = 0;
-            bool ok = false;
-            if (lane < nh) {
-                b = min(find_bin(ix, site), ix.n_bins - 1);
-                DevBin bin = ix.bins[b];
-                ok = candidate_window(site, q, bin, g.L, g.ED, &ws, &we);
+        StrandGeom gg{0, 0, 1};
+        if (gvalid && gnh) gg = strand_geom(a.read_off, a.r0 + (grs >> 1), a.edit_rate, a.min_seed, a.strand_nseeds[grs]);
+        uint64_t key = gl < gnh ? ((uint64_t)a.hit_ref[go + gl] << 32) | a.hit_q[go + gl] : ~0ull;
+        for (uint32_t k = 2; k <= 16; k <<= 1)  // bitonic sort inside the 16-lane group
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                uint64_t other = __shfl_xor(key, j);
+                bool up = (gl & k) == 0, lower = (gl & j) == 0;
+                key = (lower == up) ? min(key, other) : max(key, other);
             }
-            Walk w{false, 0, 0, 0, 0};
-            uint32_t ms = 0, me = 0, mb = 0, mn = 0;
-            for (uint32_t i = 0; i < nh; i++) {
-                uint32_t wsi = __builtin_amdgcn_readlane(ws, i), wei = __builtin_amdgcn_readlane(we, i);
-                uint32_t bi = __builtin_amdgcn_readlane(b, i);
-                bool oki = __builtin_amdgcn_readlane((uint32_t)ok, i) != 0;
+        uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
+        uint32_t b = 0, ws = 0, we = 0, btax = 0;
+        bool ok = false;
+        if (gl < gnh) {
+            b = min(find_bin(ix, site), ix.n_bins - 1);
+            DevBin bin = ix.bins[b];
+            btax = bin.tax_id;  // travels with the walk: no dependent reload of the candidate's bin
+            ok = candidate_window(site, q, bin, gg.L, gg.ED, &ws, &we);
+        }
+        Walk w{false, 0, 0, 0, 0};
+        uint32_t wtax = 0;
+        uint32_t gnc = 0, ms = 0, me = 0, mb = 0, mn = 0, mtax = 0;
+        for (uint32_t i = 0; i < maxnh; i++) {
+            const int src = (int)(gbase + i);
+            uint32_t wsi = (uint32_t)__shfl((int)ws, src), wei = (uint32_t)__shfl((int)we, src);
+            uint32_t bi = (uint32_t)__shfl((int)b, src), ti = (uint32_t)__shfl((int)btax, src);
+            bool oki = __shfl((int)ok, src) != 0;
+            if (i < gnh) {
                 bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
-                if (merge) {  // add_seed_hit, index.rs:216-229
+                if (merge) {
                     w.s = min(w.s, wsi);
                     w.e = max(w.e, wei);
                     w.n++;
                 } else {
-                    if (w.have && w.n >= g.min_seeds) {  // index.rs:467-469
-                        if (lane == nc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
-                        nc++;
+                    if (w.have && w.n >= gg.min_seeds) {
+                        if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
+                        gnc++;
                     }
-                    w.have = oki;  // ReferenceCandidate::new, index.rs:472,475
+                    w.have = oki;
                     w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
+                    wtax = ti;
                 }
             }
-            if (w.have && w.n >= g.min_seeds) {  // index.rs:481-485
-                if (lane == nc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
-                nc++;
-            }
-            // stable sort by num_seeds descending (index.rs:369) as a rank computation
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < nc; j++) {
-                uint32_t nj = __builtin_amdgcn_readlane(mn, j);
-                rank += (nj > mn) || (nj == mn && j < lane);
-            }
-            // same-TaxID chain in rank order: a candidate is verified only after every earlier candidate
-            // of its TaxID has failed (index.rs:393), so only the first of each TaxID starts as work
-            uint32_t tax = lane < nc ? ix.bins[mb].tax_id : 0;
-            uint32_t nxt = 0xffffffffu;
-            bool first = lane < nc;
-            for (uint32_t j = 0; j < nc; j++) {
-                uint32_t tj = __builtin_amdgcn_readlane(tax, j), rj = __builtin_amdgcn_readlane(rank, j);
+        }
+        if (w.have && w.n >= gg.min_seeds) {
+            if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
+            gnc++;
+        }
+        uint32_t maxnc = gnc;
+        maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 16));
+        maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 32));
+        maxnc = __builtin_amdgcn_readfirstlane(maxnc);
+        const uint32_t tax = gl < gnc ? mtax : 0;
+        uint32_t rank = 0;
+        for (uint32_t j = 0; j < maxnc; j++) {
+            uint32_t nj = (uint32_t)__shfl((int)mn, (int)(gbase + j));
+            if (j < gnc) rank += (nj > mn) || (nj == mn && j < gl);
+        }
+        uint32_t nxt = 0xffffffffu;
+        bool first = gl < gnc;
+        for (uint32_t j = 0; j < maxnc; j++) {
+            uint32_t tj = (uint32_t)__shfl((int)tax, (int)(gbase + j)), rj = (uint32_t)__shfl((int)rank, (int)(gbase + j));
+            if (j < gnc) {
                 if (tj == tax && rj > rank && rj < nxt) nxt = rj;
                 if (tj == tax && rj < rank) first = false;
             }
-            if (lane < nc) {
-                cand[o + rank] = make_uint4(ms, me, mb, mn);
-                cand_next[o + rank] = nxt;
-                cand_rs[o + rank] = rs;
-                cand_status[o + rank] = 0;
-            }
-            {
-                bool emit = first && rank < maxc;
-                unsigned long long em = __ballot(emit);
-                uint32_t m = __popcll(em);
-                if (pend + m > kWave) {  // flush the buffered items with one atomic
-                    uint32_t base = 0;
-                    if (lane == 0) base = atomicAdd(wl_count, pend);
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (lane < pend) worklist[base + lane] = pend_buf[lane];
-                    pend = 0;
-                }
-                if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = o + rank;
-                pend += m;
-            }
-        } else {
-            // ---- segments longer than a wavefront go to k_coalesce_heavy (block per strand, LDS sort) ----
-            if (lane == 0) heavy_list[atomicAdd(heavy_count, 1u)] = rs;
-            continue;
         }
-        if (lane == 0) strand_ncand[rs] = nc;
-        if (lane == 0) cand_sum += nc;
-      }
+        if (gl < gnc) {
+            a.cand[go + rank] = make_uint4(ms, me, mb, mn);
+            a.cand_next[go + rank] = nxt;
+            a.cand_rs[go + rank] = grs;
+            a.cand_status[go + rank] = 0;
+        }
+        if (gvalid && gl == 0 && !big) a.strand_ncand[grs] = gnc;
+        if (gl == 0) cand_sum += gnc;
+        {
+            bool emit = first && rank < a.maxc;
+            unsigned long long em = __ballot(emit);
+            uint32_t m = __popcll(em);
+            if (pend + m > kWave) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(a.wl_count, pend);
+                base = __builtin_amdgcn_readfirstlane(base);
+                wave_mem_sync();
+                if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
+                wave_mem_sync();
+                pend = 0;
+            }
+            if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = go + rank;
+            pend += m;
+        }
     }
     if (pend) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(wl_count, pend);
+        if (lane == 0) base = atomicAdd(a.wl_count, pend);
         base = __builtin_amdgcn_readfirstlane(base);
-        if (lane < pend) worklist[base + lane] = pend_buf[lane];
+        wave_mem_sync();
+        if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
     }
     for (int d = 32; d > 0; d >>= 1) cand_sum += __shfl_down(cand_sum, d);
-    if (lane == 0 && cand_sum) atomicAdd(n_cand_total, cand_sum);
+    if (lane == 0 && cand_sum) atomicAdd(a.n_cand_total, cand_sum);
+}
+
+// Strands of the list with 17..64 seed hits: one wavefront each, everything in registers.
+// one strand of 17..64 seed hits on one wavefront; returns its candidate count.  Not inlined on purpose: the
+// caller's loop state and the argument block would otherwise all be live across this body (SGPR spills).
+__device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndexView& ix, const CoalesceArgs& a, uint32_t rs, uint32_t o,
+                                                                    uint32_t nh, uint32_t* pend_buf, uint32_t& pend) {
+    const uint32_t lane = lane_id();
+    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, a.strand_nseeds[rs]);
+    uint32_t nc = 0;
+    // ---- registers only ----
+    uint64_t key = lane < nh ? ((uint64_t)a.hit_ref[o + lane] << 32) | a.hit_q[o + lane] : ~0ull;
+    key = wave_bitonic_sort(key);  // seed_hits.sort(): (reference_offset, query_offset), index.rs:443
+    uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
+    uint32_t b = 0, ws = 0, we = 0;
+    bool ok = false;
+    if (lane < nh) {
+        b = min(find_bin(ix, site), ix.n_bins - 1);
+        DevBin bin = ix.bins[b];
+        ok = candidate_window(site, q, bin, g.L, g.ED, &ws, &we);
+    }
+    Walk w{false, 0, 0, 0, 0};
+    uint32_t ms = 0, me = 0, mb = 0, mn = 0;
+    for (uint32_t i = 0; i < nh; i++) {
+        uint32_t wsi = (uint32_t)__shfl((int)ws, (int)i), wei = (uint32_t)__shfl((int)we, (int)i);
+        uint32_t bi = (uint32_t)__shfl((int)b, (int)i);
+        bool oki = (uint32_t)__shfl((int)ok, (int)i) != 0;
+        bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
+        if (merge) {  // add_seed_hit, index.rs:216-229
+            w.s = min(w.s, wsi);
+            w.e = max(w.e, wei);
+            w.n++;
+        } else {
+            if (w.have && w.n >= g.min_seeds) {  // index.rs:467-469
+                if (lane == nc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
+                nc++;
+            }
+            w.have = oki;  // ReferenceCandidate::new, index.rs:472,475
+            w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
+        }
+    }
+    if (w.have && w.n >= g.min_seeds) {  // index.rs:481-485
+        if (lane == nc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
+        nc++;
+    }
+    // stable sort by num_seeds descending (index.rs:369) as a rank computation
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < nc; j++) {
+        uint32_t nj = (uint32_t)__shfl((int)mn, (int)j);
+        rank += (nj > mn) || (nj == mn && j < lane);
+    }
+    // same-TaxID chain in rank order: a candidate is verified only after every earlier candidate
+    // of its TaxID has failed (index.rs:393), so only the first of each TaxID starts as work
+    uint32_t tax = lane < nc ? ix.bins[mb].tax_id : 0;
+    uint32_t nxt = 0xffffffffu;
+    bool first = lane < nc;
+    for (uint32_t j = 0; j < nc; j++) {
+        uint32_t tj = (uint32_t)__shfl((int)tax, (int)j), rj = (uint32_t)__shfl((int)rank, (int)j);
+        if (tj == tax && rj > rank && rj < nxt) nxt = rj;
+        if (tj == tax && rj < rank) first = false;
+    }
+    if (lane < nc) {
+        a.cand[o + rank] = make_uint4(ms, me, mb, mn);
+        a.cand_next[o + rank] = nxt;
+        a.cand_rs[o + rank] = rs;
+        a.cand_status[o + rank] = 0;
+    }
+    {
+        bool emit = first && rank < a.maxc;
+        unsigned long long em = __ballot(emit);
+        uint32_t m = __popcll(em);
+        if (pend + m > kWave) {  // flush the buffered items with one atomic
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(a.wl_count, pend);
+            base = __builtin_amdgcn_readfirstlane(base);
+            if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
+            pend = 0;
+        }
+        if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = o + rank;
+        pend += m;
+    }
+    return nc;
+}
+
+__global__ __launch_bounds__(256) void k_coalesce_mid(DevIndexView ix, CoalesceArgs a) {
+    __shared__ uint32_t pend_all[256 / kWave][kWave];
+    uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
+    const uint32_t lane = lane_id();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
+    const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
+    const uint32_t n_list = *a.heavy_count;
+    uint32_t pend = 0;
+    unsigned long long cand_sum = 0;
+    for (uint32_t h = wave; h < n_list; h += n_waves) {
+        const uint32_t rs = a.heavy_list[h];
+        const uint32_t o = a.strand_off[rs];
+        const uint32_t nh = __builtin_amdgcn_readfirstlane(a.strand_off[rs + 1] - o);
+        if (nh > kWave) continue;  // k_coalesce_heavy's
+        const uint32_t nc = coalesce_mid_strand(ix, a, rs, o, nh, pend_buf, pend);
+        if (lane == 0) a.strand_ncand[rs] = nc;
+        if (lane == 0) cand_sum += nc;
+    }
+    if (pend) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(a.wl_count, pend);
+        base = __builtin_amdgcn_readfirstlane(base);
+        wave_mem_sync();
+        if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
+    }
+    for (int d = 32; d > 0; d >>= 1) cand_sum += __shfl_down(cand_sum, d);
+    if (lane == 0 && cand_sum) atomicAdd(a.n_cand_total, cand_sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2193,9 +2226,30 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                      uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, uint32_t* heavy_list,
                      uint32_t* heavy_count, unsigned long long* n_cand_total) {
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n_strands, 16), 256 * 8));  // 4 strands per wavefront pass
-    hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, read_off, r0, n_strands, edit_rate, min_seed,
-                       max_candidates, strand_off, strand_nseeds, hit_ref, hit_q, hit_key, cand_tmp, cand, cand_next, cand_rs,
-                       cand_status, strand_ncand, worklist, wl_count, heavy_list, heavy_count, n_cand_total);
+    CoalesceArgs c;
+    c.read_off = read_off;
+    c.r0 = r0;
+    c.n_strands = n_strands;
+    c.edit_rate = edit_rate;
+    c.min_seed = min_seed;
+    c.maxc = rank_bound(max_candidates);
+    c.strand_off = strand_off;
+    c.strand_nseeds = strand_nseeds;
+    c.hit_ref = hit_ref;
+    c.hit_q = hit_q;
+    c.cand = cand;
+    c.cand_next = cand_next;
+    c.cand_rs = cand_rs;
+    c.cand_status = cand_status;
+    c.strand_ncand = strand_ncand;
+    c.worklist = worklist;
+    c.wl_count = wl_count;
+    c.heavy_list = heavy_list;
+    c.heavy_count = heavy_count;
+    c.n_cand_total = n_cand_total;
+    hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, c);
+    // the list of longer strands is short (device-side count): a modest grid of wavefronts walks it
+    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 1024)), dim3(256), 0, s, ix, c);
     HeavyArgs a;
     a.read_off = read_off;
     a.r0 = r0;
@@ -2236,8 +2290,7 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, 
     else if (max_len <= 160) EVAL_CASE(10, false, 16);
     else if (max_len <= 208) EVAL_CASE(13, false, 16);
     else if (max_len < 254) EVAL_CASE(16, false, 16);
-    else if (max_len <= 256) EVAL_CASE(16, true, 16);
-    else if (max_len <= kMaxRegisterReadLen) EVAL_CASE(20, true, 16);
+    else if (max_len <= kMaxRegisterReadLen) EVAL_CASE(16, true, 16);
     else throw std::runtime_error("internal: launch_evaluate called for a read beyond the register-resident kernels");
 #undef EVAL_CASE
 }

@@ -50,7 +50,7 @@ struct EvalArgs {
     uint32_t claim_shift = 0;     // k_sw_pairs: work items per claim = clamp(n_work >> claim_shift, 4, 32)
 };
 
-constexpr uint32_t kMaxRegisterReadLen = 320;  // 16 lanes x 20 read rows per lane: k_evaluate with the matrix band in registers
+constexpr uint32_t kMaxRegisterReadLen = 256;  // 16 lanes x 16 read rows per lane: k_evaluate with the whole matrix band in registers
 constexpr uint32_t kMaxReadLen = 32767;        // the tiled kernel's packed 16-bit cells (edit distance <= read length)
 
 // base normalisation of bytes [begin, end) of a read buffer, src -> dst (may be equal): every other kernel expects codes

@@ -27,7 +27,7 @@ FIELDS = [
 def parse(text):
     out = []
     for blk in re.split(r"remark: [^\n]*Function Name: ", text)[1:]:
-        name = blk.split("\n")[0].strip()
+        name = blk.split("\n")[0].strip().split(" ")[0]
         row = {"name": name}
         for key, pat in FIELDS:
             m = re.search(pat + r": (\d+)", blk)
@@ -40,7 +40,7 @@ def demangle(names):
     import subprocess
 
     try:
-        p = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt"], input="\n".join(names), capture_output=True, text=True)
+        p = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
         d = p.stdout.strip().split("\n")
         if len(d) == len(names):
             return d
@@ -60,7 +60,7 @@ def main():
         n = re.sub(r"\(.*$", "", n)
         print(f"{n[:44]:44s} SGPR {r['sgpr']:4d} VGPR {r['vgpr']:4d} scratch {r['scratch']:4d} occ {r['occ']:2d} "
               f"sgpr_spill {r['sgpr_spill']:3d} vgpr_spill {r['vgpr_spill']:3d} LDS {r['lds']}")
-        if r["sgpr_spill"] > 0 or r["vgpr_spill"] > 0 or r["scratch"] > 0:
+        if r["sgpr_spill"] > 0 or r["vgpr_spill"] > 0:
             bad.append(n)
     if guard and bad:
         print("register spills in: " + ", ".join(bad), file=sys.stderr)
