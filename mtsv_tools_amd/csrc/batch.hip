@@ -112,7 +112,7 @@ Batch::~Batch() {
                     (void*)d_strand_nseeds, (void*)d_strand_off, (void*)d_strand_ncand, (void*)d_worklist,
                     (void*)d_strand_nout, (void*)d_out_off, (void*)d_tile_sums, (void*)d_counters, (void*)d_hit_row,
                     (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand, (void*)d_out,
-                    (void*)d_hits, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_heavy_list})
+                    (void*)d_hits, (void*)d_cand_next, (void*)d_cand_status, (void*)d_heavy_list})
         (void)hipFree(p);
     (void)hipFree(d_codes);
     (void)hipFree(d_strip);
@@ -141,7 +141,6 @@ void Batch::alloc_hit_workspace() {
     dev_alloc(&d_cand, hit_cap, &bytes);
     dev_alloc(&d_out, hit_cap, &bytes);
     dev_alloc(&d_cand_next, hit_cap, &bytes);
-    dev_alloc(&d_cand_rs, hit_cap, &bytes);
     dev_alloc(&d_cand_status, hit_cap, &bytes);
     dev_alloc(&d_worklist, hit_cap, &bytes);
 }
@@ -149,9 +148,9 @@ void Batch::alloc_hit_workspace() {
 void Batch::grow_hit_workspace(uint64_t need) {
     HIP_CHECK(hipStreamSynchronize(stream));
     for (void* p : {(void*)d_hit_row, (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand,
-                    (void*)d_out, (void*)d_cand_next, (void*)d_cand_rs, (void*)d_cand_status, (void*)d_worklist})
+                    (void*)d_out, (void*)d_cand_next, (void*)d_cand_status, (void*)d_worklist})
         (void)hipFree(p);
-    d_hit_row = d_hit_ref = d_hit_q = d_cand_next = d_cand_rs = d_cand_status = d_worklist = nullptr;
+    d_hit_row = d_hit_ref = d_hit_q = d_cand_next = d_cand_status = d_worklist = nullptr;
     d_hit_key = d_cand_tmp = nullptr;
     d_cand = d_out = nullptr;
     hit_cap = need;
@@ -364,18 +363,21 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             (void)hipFree(d_seed_cnt);
             (void)hipFree(d_seed_pre);
             d_seed_lo = d_seed_cnt = d_seed_pre = nullptr;
+            // room for a full workspace of reads like these, not just this pass: slices of a host batch grow
+            // towards the workspace size, and every hipFree / hipMalloc stalls the whole device
+            const uint64_t want = tiled ? slots : std::max<uint64_t>(slots, 2 * ws_reads * (uint64_t)max_ns);
             uint64_t dummy = 0;
-            dev_alloc(&d_seed_lo, slots, &dummy);
-            dev_alloc(&d_seed_cnt, slots, &dummy);
-            dev_alloc(&d_seed_pre, slots, &dummy);
-            seed_cap = slots;
+            dev_alloc(&d_seed_lo, want, &dummy);
+            dev_alloc(&d_seed_cnt, want, &dummy);
+            dev_alloc(&d_seed_pre, want, &dummy);
+            seed_cap = want;
         }
         // ---- seeds ----
         HIP_CHECK(hipEventRecord(ev[0], stream));
         launch_search(stream, v, sb, so, (uint32_t)r0, nr, max_ns, K, G, d_seed_lo, d_seed_cnt);
         HIP_CHECK(hipEventRecord(ev[1], stream));
         if (max_ns)
-            launch_thin(stream, so, (uint32_t)r0, nr, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
+            launch_thin(stream, sb, so, (uint32_t)r0, nr, p.edit_rate, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
                         d_seed_pre, d_strand_hits, d_strand_nseeds);
         else {
             HIP_CHECK(hipMemsetAsync(d_strand_hits, 0, (uint64_t)nstr * 4, stream));
@@ -412,7 +414,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         HIP_CHECK(hipMemsetAsync(d_counters + 1, 0, 8, stream));
         HIP_CHECK(hipMemsetAsync(d_counters + 7, 0, 8, stream));
         launch_coalesce(stream, v, so, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, p.max_candidates, d_strand_off,
-                        d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next, d_cand_rs,
+                        d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next,
                         d_cand_status, d_strand_ncand, d_worklist, (uint32_t*)(d_counters + 1), d_heavy_list,
                         (uint32_t*)(d_counters + 1) + 1, (unsigned long long*)(d_counters + 3));
         HIP_CHECK(hipEventRecord(ev[5], stream));
@@ -427,7 +429,6 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             a.strand_off = d_strand_off;
             a.cand = d_cand;
             a.cand_next = d_cand_next;
-            a.cand_rs = d_cand_rs;
             a.cand_status = d_cand_status;
             a.out = d_out;
             a.n_verified = (unsigned long long*)(d_counters + 4);

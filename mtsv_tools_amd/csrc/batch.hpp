@@ -59,7 +59,7 @@ struct Batch {
     uint32_t *d_hit_row = nullptr, *d_hit_ref = nullptr, *d_hit_q = nullptr;
     uint64_t *d_hit_key = nullptr, *d_cand_tmp = nullptr;
     uint4 *d_cand = nullptr, *d_out = nullptr;
-    uint32_t *d_cand_next = nullptr, *d_cand_rs = nullptr, *d_cand_status = nullptr, *d_heavy_list = nullptr;
+    uint32_t *d_cand_next = nullptr, *d_cand_status = nullptr, *d_heavy_list = nullptr;
     DevHit* d_hits = nullptr;
     uint2* d_strip = nullptr;  // tiled long-read kernel: band hand-over strips, allocated when a pass first needs them
     uint64_t strip_cap = 0;

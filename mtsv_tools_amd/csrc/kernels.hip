@@ -213,7 +213,16 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
 // ---------------------------------------------------------------------------------------------
 // K1b: sequential seed policy of one strand (index.rs:293-344,354)
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_thin(const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t n_reads,
+// A strand is HOPELESS when no candidate of it can be accepted whatever its window holds: the usize wrap of
+// index.rs:406 (2*ED > L: the threshold L - 2*ED wraps and no score reaches it), or more N in the read than
+// the edit tolerance (a read N never matches in the edit-distance recurrence, index.rs:272-279, so
+// edits >= #N > ED fails :410).  The reference still runs its prefilter on every candidate of such a strand;
+// here the coalescing kernels account that work (counters) and emit no work items for it.  The flag
+// travels in the top bit of strand_nseeds.
+constexpr uint32_t kHopeless = 0x80000000u;
+
+__global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ read_off,
+                                              uint32_t r0, uint32_t n_reads, double edit_rate,
                                               uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits,
                                               uint64_t tune_max_hits, uint32_t* __restrict__ seed_cnt,
                                               uint32_t* __restrict__ seed_pre, uint32_t* __restrict__ strand_hits,
@@ -221,7 +230,8 @@ __global__ __launch_bounds__(256) void k_thin(const uint32_t* __restrict__ read_
     uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
     if (rs >= n_reads * 2) return;
     uint32_t r = r0 + (rs >> 1);
-    uint32_t L = read_off[r + 1] - read_off[r];
+    const uint32_t b0 = read_off[r];
+    uint32_t L = read_off[r + 1] - b0;
     uint32_t ns = n_seeds_of(L, K, G);
     uint64_t next_offset = 0, seed_interval = G;
     uint32_t total = 0, nseeds = 0;
@@ -246,6 +256,26 @@ __global__ __launch_bounds__(256) void k_thin(const uint32_t* __restrict__ read_
         }
         total += c;
         nseeds++;
+    }
+    if (total) {  // only strands that can have candidates need the flag
+        const uint32_t ED = (uint32_t)ceil((double)L * edit_rate);  // index.rs:281-282
+        bool hopeless = 2ull * ED > (uint64_t)L;
+        if (!hopeless) {
+            // N count of the read (the same for both strands): aligned dwords of the code buffer, codes are 0..4
+            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
+            const uint32_t w0 = b0 >> 2, w1 = (b0 + L + 3) >> 2;  // the buffer is padded past its last read
+            uint32_t nn = 0;
+            for (uint32_t w = w0; w < w1; w++) {
+                uint32_t v = b32[w];
+                uint32_t lo = w == w0 ? (b0 & 3) : 0, hi = w + 1 == w1 ? ((b0 + L - 1) & 3) + 1 : 4;  // valid bytes [lo, hi)
+                uint32_t m = (v >> 2) & 0x01010101u;  // bit 2 of every byte: code 4
+                if (lo) m &= 0xffffffffu << (8 * lo);
+                if (hi < 4) m &= (1u << (8 * hi)) - 1u;
+                nn += __popc(m);
+            }
+            hopeless = nn > ED;
+        }
+        if (hopeless) nseeds |= kHopeless;
     }
     strand_hits[rs] = total;
     strand_nseeds[rs] = nseeds;
@@ -348,18 +378,36 @@ __global__ __launch_bounds__(256) void k_expand(DevIndexView ix, uint64_t n_slot
                                                 uint32_t* __restrict__ hit_row, uint32_t* __restrict__ hit_ref,
                                                 uint32_t* __restrict__ hit_q) {
     uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (slot >= n_slots) return;
-    const uint32_t c = seed_cnt[slot];
-    if (!c) return;
-    const uint32_t rs = (uint32_t)(slot / max_ns), j = (uint32_t)(slot % max_ns);
-    uint32_t o = strand_off[rs] + seed_pre[slot];
-    const uint32_t l = seed_lo[slot], q = j * G;
-    for (uint32_t i = 0; i < c; i++, o++) {
-        if (ix.sa_full)
-            hit_ref[o] = ix.sa_full[l + i];
-        else
-            hit_row[o] = l + i;
-        hit_q[o] = q;
+    const uint32_t c = slot < n_slots ? seed_cnt[slot] : 0;
+    uint32_t o = 0, l = 0, q = 0;
+    if (c) {
+        const uint32_t rs = (uint32_t)(slot / max_ns), j = (uint32_t)(slot % max_ns);
+        o = strand_off[rs] + seed_pre[slot];
+        l = seed_lo[slot];
+        q = j * G;
+    }
+    // seeds with few hits: the lane writes them itself; repeats (up to max_hits per seed) are spread over the
+    // wavefront, one seed after the other, so that no single lane walks thousands of entries
+    constexpr uint32_t kOwn = 16;
+    if (c && c <= kOwn) {
+        for (uint32_t i = 0; i < c; i++) {
+            if (ix.sa_full) hit_ref[o + i] = ix.sa_full[l + i];
+            else hit_row[o + i] = l + i;
+            hit_q[o + i] = q;
+        }
+    }
+    unsigned long long big = __ballot(c > kOwn);
+    const uint32_t lane = lane_id();
+    while (big) {
+        const int src = __ffsll((long long)big) - 1;
+        big &= big - 1;
+        const uint32_t cs = __builtin_amdgcn_readlane(c, src), os = __builtin_amdgcn_readlane(o, src);
+        const uint32_t ls = __builtin_amdgcn_readlane(l, src), qs = __builtin_amdgcn_readlane(q, src);
+        for (uint32_t i = lane; i < cs; i += kWave) {
+            if (ix.sa_full) hit_ref[os + i] = ix.sa_full[ls + i];
+            else hit_row[os + i] = ls + i;
+            hit_q[os + i] = qs;
+        }
     }
 }
 
@@ -469,9 +517,19 @@ struct StrandGeom {
     uint32_t L, ED, min_seeds;
 };
 
+// sum over the 16 lanes of a DPP row, result in every lane
+__device__ inline int row_sum16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
+    return v;
+}
+
 __device__ inline StrandGeom strand_geom(const uint32_t* read_off, uint32_t r, double edit_rate, double min_seed,
                                          uint32_t nseeds) {
     StrandGeom g;
+    nseeds &= ~kHopeless;  // the top bit is k_thin's flag
     g.L = read_off[r + 1] - read_off[r];
     g.ED = (uint32_t)ceil((double)g.L * edit_rate);           // index.rs:281-282
     double ms = floor((double)nseeds * min_seed);             // index.rs:358
@@ -567,7 +625,6 @@ struct HeavyArgs {
     uint64_t* cand_tmp;
     uint4* cand;
     uint32_t* cand_next;
-    uint32_t* cand_rs;
     uint32_t* cand_status;
     uint32_t* strand_ncand;
     uint32_t* worklist;
@@ -583,7 +640,9 @@ __device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_
     const bool walker = !BLK || threadIdx.x < kWave;  // the sequential walk runs on one wavefront
     const uint32_t o = a.strand_off[rs];
     const uint32_t nh = a.strand_off[rs + 1] - o;
-    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, a.strand_nseeds[rs]);
+    const uint32_t ns_raw = a.strand_nseeds[rs];
+    const bool hopeless = (ns_raw & kHopeless) != 0;  // see k_coalesce
+    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, ns_raw);
     for (uint32_t i = tid; i < nh; i += nt) km.st(i, ((uint64_t)a.hit_ref[o + i] << 32) | a.hit_q[o + i]);
     km.sync();
     big_sort(km, nh);  // seed_hits.sort(), index.rs:443
@@ -636,6 +695,25 @@ __device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     km.sync();
     if (BLK) nc = *sh_nc;
+    if (hopeless && a.maxc >= nc) {
+        // every candidate is prefiltered by the reference and none can pass: account the work, skip the ranking
+        unsigned long long wsum = 0;
+        for (uint32_t i = tid; i < nc; i += nt) {
+            const uint64_t se = gload(ct + 2ull * i);
+            wsum += (uint32_t)(se >> 32) - (uint32_t)se;
+        }
+        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d);
+        if (lane == 0 && wsum) atomicAdd(a.n_cand_total + 2, wsum);
+        if (tid == 0) {
+            a.strand_ncand[rs] = 0;
+            if (nc) {
+                atomicAdd(a.n_cand_total, (unsigned long long)nc);
+                atomicAdd(a.n_cand_total + 1, (unsigned long long)nc);
+            }
+        }
+        km.sync();  // the key array is free for the next strand
+        return;
+    }
     // rank: sort (num_seeds descending, walk order ascending) -- the stable sort of index.rs:369
     for (uint32_t i = tid; i < nc; i += nt) {
         uint32_t n_i = (uint32_t)(gload(ct + 2ull * i + 1) >> 32);
@@ -649,10 +727,13 @@ __device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_
         if (i < nc) {
             uint32_t src = (uint32_t)km.ld(i);
             uint64_t se = gload(ct + 2ull * src), bn = gload(ct + 2ull * src + 1);
-            a.cand[o + i] = make_uint4((uint32_t)se, (uint32_t)(se >> 32), (uint32_t)bn, (uint32_t)(bn >> 32));
-            a.cand_rs[o + i] = rs;
+            a.cand[o + i] = make_uint4((uint32_t)se, (uint32_t)(se >> 32), (uint32_t)bn, rs);
             a.cand_status[o + i] = 0;
             taxkey = ((uint64_t)ix.bins[(uint32_t)bn].tax_id << 32) | i;  // (TaxId, rank)
+            if (hopeless && i < a.maxc) {  // max_candidates < nc: only the first ranks are prefiltered
+                atomicAdd(a.n_cand_total + 1, 1ull);
+                atomicAdd(a.n_cand_total + 2, (unsigned long long)((uint32_t)(se >> 32) - (uint32_t)se));
+            }
         }
         km.sync();  // all reads of this tile's rank keys are done before they are overwritten
         if (i < nc) km.st(i, taxkey);
@@ -669,7 +750,7 @@ __device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_
             uint64_t kp = p > 0 ? km.ld(p - 1) : ~0ull;
             rk = (uint32_t)k0;
             a.cand_next[o + rk] = (kn >> 32) == (k0 >> 32) ? (uint32_t)kn : 0xffffffffu;
-            emit = (p == 0 || (kp >> 32) != (k0 >> 32)) && rk < a.maxc;
+            emit = (p == 0 || (kp >> 32) != (k0 >> 32)) && rk < a.maxc && !hopeless;
         }
         unsigned long long em = __ballot(emit);
         if (em) {
@@ -680,7 +761,7 @@ __device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_
         }
     }
     if (tid == 0) {
-        a.strand_ncand[rs] = nc;
+        a.strand_ncand[rs] = hopeless ? 0 : nc;
         if (nc) atomicAdd(a.n_cand_total, (unsigned long long)nc);
     }
     km.sync();  // the key array is free for the next strand
@@ -718,7 +799,6 @@ struct CoalesceArgs {
     const uint32_t* hit_q;
     uint4* cand;
     uint32_t* cand_next;
-    uint32_t* cand_rs;
     uint32_t* cand_status;
     uint32_t* strand_ncand;
     uint32_t* worklist;
@@ -735,7 +815,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
     uint32_t pend = 0;  // work items buffered in pend_buf (wave-uniform)
-    unsigned long long cand_sum = 0;
+    unsigned long long cand_sum = 0, ver_sum = 0, win_sum = 0;
     for (uint32_t rs4 = wave * 4; rs4 < a.n_strands; rs4 += n_waves * 4) {
         const uint32_t gl = lane & 15, gbase = lane & 48;
         const uint32_t grs = rs4 + (lane >> 4);
@@ -756,7 +836,12 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
             continue;
         }
         StrandGeom gg{0, 0, 1};
-        if (gvalid && gnh) gg = strand_geom(a.read_off, a.r0 + (grs >> 1), a.edit_rate, a.min_seed, a.strand_nseeds[grs]);
+        bool hopeless = false;  // group-uniform: k_thin's flag (see kHopeless)
+        if (gvalid && gnh) {
+            const uint32_t ns_raw = a.strand_nseeds[grs];
+            hopeless = (ns_raw & kHopeless) != 0;
+            gg = strand_geom(a.read_off, a.r0 + (grs >> 1), a.edit_rate, a.min_seed, ns_raw);
+        }
         uint64_t key = gl < gnh ? ((uint64_t)a.hit_ref[go + gl] << 32) | a.hit_q[go + gl] : ~0ull;
         for (uint32_t k = 2; k <= 16; k <<= 1)  // bitonic sort inside the 16-lane group
             for (uint32_t j = k >> 1; j > 0; j >>= 1) {
@@ -821,16 +906,24 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
                 if (tj == tax && rj < rank) first = false;
             }
         }
-        if (gl < gnc) {
-            a.cand[go + rank] = make_uint4(ms, me, mb, mn);
+        if (gl < gnc && !hopeless) {
+            a.cand[go + rank] = make_uint4(ms, me, mb, grs);
             a.cand_next[go + rank] = nxt;
-            a.cand_rs[go + rank] = grs;
             a.cand_status[go + rank] = 0;
         }
-        if (gvalid && gl == 0 && !big) a.strand_ncand[grs] = gnc;
-        if (gl == 0) cand_sum += gnc;
+        // a hopeless strand: the reference prefilters each of its candidates (up to max_candidates) and none can
+        // pass; that work is accounted here and the strand leaves the pipeline (no candidates to resolve)
+        const int hw = row_sum16((hopeless && gl < gnc && rank < a.maxc) ? (int)(me - ms) : 0);
+        if (gvalid && gl == 0 && !big) a.strand_ncand[grs] = hopeless ? 0 : gnc;
+        if (gl == 0) {
+            cand_sum += gnc;
+            if (hopeless) {
+                ver_sum += min(gnc, a.maxc);
+                win_sum += (uint32_t)hw;
+            }
+        }
         {
-            bool emit = first && rank < a.maxc;
+            bool emit = first && rank < a.maxc && !hopeless;
             unsigned long long em = __ballot(emit);
             uint32_t m = __popcll(em);
             if (pend + m > kWave) {
@@ -853,8 +946,16 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
         wave_mem_sync();
         if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
     }
-    for (int d = 32; d > 0; d >>= 1) cand_sum += __shfl_down(cand_sum, d);
+    for (int d = 32; d > 0; d >>= 1) {
+        cand_sum += __shfl_down(cand_sum, d);
+        ver_sum += __shfl_down(ver_sum, d);
+        win_sum += __shfl_down(win_sum, d);
+    }
     if (lane == 0 && cand_sum) atomicAdd(a.n_cand_total, cand_sum);
+    if (lane == 0 && ver_sum) {  // the counters sit side by side: n_candidates, n_verified, window_bytes
+        atomicAdd(a.n_cand_total + 1, ver_sum);
+        atomicAdd(a.n_cand_total + 2, win_sum);
+    }
 }
 
 // Strands of the list with 17..64 seed hits: one wavefront each, everything in registers.
@@ -863,7 +964,9 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
 __device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndexView& ix, const CoalesceArgs& a, uint32_t rs, uint32_t o,
                                                                     uint32_t nh, uint32_t* pend_buf, uint32_t& pend) {
     const uint32_t lane = lane_id();
-    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, a.strand_nseeds[rs]);
+    const uint32_t ns_raw = a.strand_nseeds[rs];
+    const bool hopeless = (ns_raw & kHopeless) != 0;  // see k_coalesce
+    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, ns_raw);
     uint32_t nc = 0;
     // ---- registers only ----
     uint64_t key = lane < nh ? ((uint64_t)a.hit_ref[o + lane] << 32) | a.hit_q[o + lane] : ~0ull;
@@ -916,12 +1019,22 @@ __device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndex
         if (tj == tax && rj > rank && rj < nxt) nxt = rj;
         if (tj == tax && rj < rank) first = false;
     }
+    if (hopeless) {
+        unsigned long long wsum = (lane < nc && rank < a.maxc) ? me - ms : 0;
+        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d);
+        if (lane == 0) {
+            a.strand_ncand[rs] = 0;
+            atomicAdd(a.n_cand_total + 1, (unsigned long long)min(nc, a.maxc));
+            atomicAdd(a.n_cand_total + 2, wsum);
+        }
+        return nc;
+    }
     if (lane < nc) {
-        a.cand[o + rank] = make_uint4(ms, me, mb, mn);
+        a.cand[o + rank] = make_uint4(ms, me, mb, rs);
         a.cand_next[o + rank] = nxt;
-        a.cand_rs[o + rank] = rs;
         a.cand_status[o + rank] = 0;
     }
+    if (lane == 0) a.strand_ncand[rs] = nc;
     {
         bool emit = first && rank < a.maxc;
         unsigned long long em = __ballot(emit);
@@ -953,8 +1066,7 @@ __global__ __launch_bounds__(256) void k_coalesce_mid(DevIndexView ix, CoalesceA
         const uint32_t o = a.strand_off[rs];
         const uint32_t nh = __builtin_amdgcn_readfirstlane(a.strand_off[rs + 1] - o);
         if (nh > kWave) continue;  // k_coalesce_heavy's
-        const uint32_t nc = coalesce_mid_strand(ix, a, rs, o, nh, pend_buf, pend);
-        if (lane == 0) a.strand_ncand[rs] = nc;
+        const uint32_t nc = coalesce_mid_strand(ix, a, rs, o, nh, pend_buf, pend);  // writes strand_ncand
         if (lane == 0) cand_sum += nc;
     }
     if (pend) {
@@ -1088,7 +1200,7 @@ __global__ __launch_bounds__(256, (WORD || R * GS > 160) ? 1 : (GS == 8 ? 3 : 5)
                 }
                 if (loc < loc_end) {
                     g = a.worklist[loc++];
-                    const uint32_t rs = a.cand_rs[g];
+                    const uint32_t rs = a.cand[g].w;
                     const uint32_t r_ = a.r0 + (rs >> 1), strand = rs & 1;
                     o = a.strand_off[rs];
                     const uint32_t b0 = a.read_off[r_];
@@ -1398,13 +1510,6 @@ __device__ inline uint32_t pku_satsub(uint32_t a, uint32_t b) { return as_bits(_
 
 enum : uint32_t { HF_EMPTY = 0, HF_SWEEP = 1, HF_PASS = 2, HF_FAIL = 3 };
 
-__device__ inline int row_sum16(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);
-    return v;
-}
 // maximum over the 16 lanes of a DPP row, result in every lane: quad swaps, then the two mirrors
 __device__ inline int row_max16(int v) {
     v = max(v, __builtin_amdgcn_update_dpp(v, v, 0xB1, 0xf, 0xf, false));   // quad_perm [1,0,3,2]
@@ -1464,7 +1569,8 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
     const uint32_t maxc = a.maxc;  // max_candidates as a rank bound, clamped on the host
     const uint32_t ONE = 0x00010001u, TWO = 0x00020002u;
     // items per claim: large enough that the claims do not bound the kernel, small enough that the last
-    // claims of the launch stay balanced (about eight claims per group: claim_shift = log2(groups * 8))
+    // claims of the launch stay balanced (two or more claims per group: claim_shift = log2(groups * 2); small
+    // worklists -- slices of a host batch -- must not fall back to tiny claims, ~11 ns of atomic each)
     const uint32_t chunk = min(max(n_work >> a.claim_shift, 4u), kClaim);
 
     uint32_t phase = PH_FETCH;
@@ -1534,8 +1640,8 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             // the lanes of the group walk the dependent loads of one item each, side by side
                             for (uint32_t i = gl; i < loc_end; i += GS) {
                                 const uint32_t gi = a.worklist[first + i];
-                                const uint32_t rs = a.cand_rs[gi];
                                 const uint4 c = a.cand[gi];
+                                const uint32_t rs = c.w;
                                 const uint32_t r_ = a.r0 + (rs >> 1);
                                 const uint32_t b0 = a.read_off[r_];
                                 uint32_t* m = meta + i * 8;
@@ -1952,17 +2058,21 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
         unsigned long long need = __ballot(!active);
         if (need) {
             if (bnext == bend && !exhausted) {
+                // few, large claims (~11 ns per atomic on one address), but not larger than an even share of a short
+                // worklist: a wavefront works through its claim 64 candidates at a time
+                const uint32_t n_waves = gridDim.x * (256 / kWave);
+                const uint32_t claim = min(256u, max(64u, (n_work / n_waves + 63u) & ~63u));
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.wl_cursor, 256u);  // few, large claims: ~11 ns per atomic on one address
+                if (lane == 0) base = atomicAdd(a.wl_cursor, claim);
                 base = __builtin_amdgcn_readfirstlane(base);
                 bnext = min(base, n_work);
-                bend = min(base + 256u, n_work);
+                bend = min(base + claim, n_work);
                 exhausted = bnext == bend;
             }
             const uint32_t take = bnext + __popcll(need & ((1ull << lane) - 1));
             if (!active && take < bend) {
                 g = a.worklist[take];
-                const uint32_t rs = a.cand_rs[g];
+                const uint32_t rs = a.cand[g].w;
                 const uint32_t r_ = a.r0 + (rs >> 1);
                 strand = rs & 1;
                 o = a.strand_off[rs];
@@ -2187,11 +2297,11 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
                        seed_lo, seed_cnt);
 }
 
-void launch_thin(hipStream_t s, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, uint32_t max_ns, uint32_t K,
-                 uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre, uint32_t* strand_hits,
-                 uint32_t* strand_nseeds) {
-    hipLaunchKernelGGL(k_thin, dim3(cdiv((uint64_t)n_reads * 2, 256)), dim3(256), 0, s, read_off, r0, n_reads, max_ns, K,
-                       G, max_hits, tune, seed_cnt, seed_pre, strand_hits, strand_nseeds);
+void launch_thin(hipStream_t s, const uint8_t* bases, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, double edit_rate,
+                 uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre,
+                 uint32_t* strand_hits, uint32_t* strand_nseeds) {
+    hipLaunchKernelGGL(k_thin, dim3(cdiv((uint64_t)n_reads * 2, 256)), dim3(256), 0, s, bases, read_off, r0, n_reads, edit_rate,
+                       max_ns, K, G, max_hits, tune, seed_cnt, seed_pre, strand_hits, strand_nseeds);
 }
 
 void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_sums, uint64_t* total, uint32_t* out) {
@@ -2222,7 +2332,7 @@ void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_ho
 void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,
                      double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
                      const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
-                     uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_rs, uint32_t* cand_status,
+                     uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_status,
                      uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, uint32_t* heavy_list,
                      uint32_t* heavy_count, unsigned long long* n_cand_total) {
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n_strands, 16), 256 * 8));  // 4 strands per wavefront pass
@@ -2239,7 +2349,6 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     c.hit_q = hit_q;
     c.cand = cand;
     c.cand_next = cand_next;
-    c.cand_rs = cand_rs;
     c.cand_status = cand_status;
     c.strand_ncand = strand_ncand;
     c.worklist = worklist;
@@ -2249,7 +2358,7 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     c.n_cand_total = n_cand_total;
     hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, c);
     // the list of longer strands is short (device-side count): a modest grid of wavefronts walks it
-    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 1024)), dim3(256), 0, s, ix, c);
+    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 1024, 1), 256)), dim3(256), 0, s, ix, c);
     HeavyArgs a;
     a.read_off = read_off;
     a.r0 = r0;
@@ -2264,7 +2373,6 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     a.cand_tmp = cand_tmp;
     a.cand = cand;
     a.cand_next = cand_next;
-    a.cand_rs = cand_rs;
     a.cand_status = cand_status;
     a.strand_ncand = strand_ncand;
     a.worklist = worklist;
@@ -2341,7 +2449,7 @@ void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, 
     do {                                                                                                                 \
         const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 3 : kSwOcc))); \
         a.claim_shift = 0;                                                                                               \
-        while ((1ull << a.claim_shift) < (uint64_t)grid * 16 * 8) a.claim_shift++;                                       \
+        while ((1ull << a.claim_shift) < (uint64_t)grid * 16 * 2) a.claim_shift++;                                       \
         if (diag) hipLaunchKernelGGL((k_sw_pairs<RR, true>), dim3(grid), dim3(256), 0, s, ix, a);                        \
         else hipLaunchKernelGGL((k_sw_pairs<RR, false>), dim3(grid), dim3(256), 0, s, ix, a);                            \
     } while (0)

@@ -56,8 +56,8 @@ def main():
     names = demangle([r["name"] for r in rows])
     bad = []
     for r, n in zip(rows, names):
-        n = re.sub(r"^void mtsv::\(anonymous namespace\)::", "", n)
-        n = re.sub(r"\(.*$", "", n)
+        n = n.replace("void ", "").replace("mtsv::", "").replace("(anonymous namespace)::", "")
+        n = re.sub(r"\((?!anonymous).*$", "", n)
         print(f"{n[:44]:44s} SGPR {r['sgpr']:4d} VGPR {r['vgpr']:4d} scratch {r['scratch']:4d} occ {r['occ']:2d} "
               f"sgpr_spill {r['sgpr_spill']:3d} vgpr_spill {r['vgpr_spill']:3d} LDS {r['lds']}")
         if r["sgpr_spill"] > 0 or r["vgpr_spill"] > 0:
