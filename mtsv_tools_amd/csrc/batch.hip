@@ -478,6 +478,9 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     sw.worklist = wl;
                     sw.wl_count = wl_count;
                     sw.wl_cursor = (uint32_t*)(d_counters + 8);
+                    sw.wl_reverse = round == 0;
+                    sw.counters = d_counters;
+                    sw.wl_count_slot = round == 0 ? 1u : 11u + ((round - 1) & 1u);
                     sw.pass_list = pass_list;
                     sw.pass_count = (uint32_t*)(d_counters + 9);
                     if (round == 0) HIP_CHECK(hipEventRecord(ev[10], stream));

@@ -257,25 +257,37 @@ __global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases,
         total += c;
         nseeds++;
     }
-    if (total) {  // only strands that can have candidates need the flag
+    {
+        // the two strands of a read sit in neighbouring lanes (rs even / odd): the even lane counts the read's N once
+        // for both, and only when one of them has seed hits (only such strands can have candidates)
+        const bool need = total != 0;
+        const bool pair_need = need || __shfl_xor((int)need, 1) != 0;
         const uint32_t ED = (uint32_t)ceil((double)L * edit_rate);  // index.rs:281-282
         bool hopeless = 2ull * ED > (uint64_t)L;
-        if (!hopeless) {
-            // N count of the read (the same for both strands): aligned dwords of the code buffer, codes are 0..4
-            const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
-            const uint32_t w0 = b0 >> 2, w1 = (b0 + L + 3) >> 2;  // the buffer is padded past its last read
-            uint32_t nn = 0;
-            for (uint32_t w = w0; w < w1; w++) {
-                uint32_t v = b32[w];
-                uint32_t lo = w == w0 ? (b0 & 3) : 0, hi = w + 1 == w1 ? ((b0 + L - 1) & 3) + 1 : 4;  // valid bytes [lo, hi)
-                uint32_t m = (v >> 2) & 0x01010101u;  // bit 2 of every byte: code 4
-                if (lo) m &= 0xffffffffu << (8 * lo);
-                if (hi < 4) m &= (1u << (8 * hi)) - 1u;
-                nn += __popc(m);
+        uint32_t nn = 0;
+        if (pair_need && !hopeless && !(rs & 1)) {
+            // codes are 0..4, N = 4: bit 2 of every byte; aligned 16-byte groups of the code buffer (padded past its end)
+            const uint4* b128 = reinterpret_cast<const uint4*>(bases);
+            const uint32_t q0 = b0 >> 4, q1 = (b0 + L + 15) >> 4;
+            for (uint32_t qi = q0; qi < q1; qi++) {
+                const uint4 v = b128[qi];
+                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t byte0 = qi * 16 + 4 * k;  // buffer position of this dword's first byte
+                    uint32_t m = (w[k] >> 2) & 0x01010101u;
+                    // bytes outside [b0, b0 + L) belong to the neighbouring reads
+                    const int lo = (int)b0 - (int)byte0, hi = (int)(b0 + L) - (int)byte0;  // valid bytes [lo, hi) of this dword
+                    if (lo > 0) m = lo >= 4 ? 0u : (m & (0xffffffffu << (8 * lo)));
+                    if (hi < 4) m = hi <= 0 ? 0u : (m & ((1u << (8 * hi)) - 1u));
+                    nn += __popc(m);
+                }
             }
-            hopeless = nn > ED;
         }
-        if (hopeless) nseeds |= kHopeless;
+        const uint32_t from_even = (uint32_t)__shfl_xor((int)nn, 1);  // every lane takes part in the exchange
+        if (rs & 1) nn = from_even;                                     // odd lane: its read's count from the even lane
+        hopeless = hopeless || nn > ED;
+        if (need && hopeless) nseeds |= kHopeless;
     }
     strand_hits[rs] = total;
     strand_nseeds[rs] = nseeds;
@@ -1541,6 +1553,11 @@ __device__ inline void wave_lds_handoff() {
 
 // DIAG: try the lower bounds on the seed diagonal before a sweep (default; MTSV_SW_DIAG=0 launches the
 // instantiation without them, which tests use to check that bounds and sweeps decide alike).
+// k_sw_pairs reaches its counters through one base pointer (slots of batch.hip's d_counters): six separate
+// pointers cost twelve scalar registers of a kernel that sits at the SGPR file's limit.
+__device__ inline uint32_t* sw_cursor(const EvalArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + kCtrSwCursor); }
+__device__ inline uint32_t* sw_pass_count(const EvalArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + kCtrPassCount); }
+
 template <int R, bool DIAG>
 __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     constexpr int GS = 16;
@@ -1557,7 +1574,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         pend++;
         if (pend == kPend) {
             uint32_t base = 0;
-            if (gl == 0) base = atomicAdd(a.pass_count, kPend);
+            if (gl == 0) base = atomicAdd(sw_pass_count(a), kPend);
             base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
             wave_lds_handoff();  // lane 0's buffered entries are read by the whole group
             for (uint32_t i = gl; i < kPend; i += GS) a.pass_list[base + i] = pend_buf[i];
@@ -1565,7 +1582,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
             pend = 0;
         }
     };
-    const uint32_t n_work = *a.wl_count;
+    const uint32_t n_work = *reinterpret_cast<const uint32_t*>(a.counters + a.wl_count_slot);
     const uint32_t maxc = a.maxc;  // max_candidates as a rank bound, clamped on the host
     const uint32_t ONE = 0x00010001u, TWO = 0x00020002u;
     // items per claim: large enough that the claims do not bound the kernel, small enough that the last
@@ -1632,14 +1649,17 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             // One atomic per `chunk` items: atomics on one address complete at ~11 ns each on
                             // this chip, so 4 items per claim put a floor of 55 ms under 20 M work items.
                             uint32_t base = 0;
-                            if (gl == 0) base = atomicAdd(a.wl_cursor, chunk);
+                            if (gl == 0) base = atomicAdd(sw_cursor(a), chunk);
                             base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
                             const uint32_t first = min(base, n_work);
                             loc = 0;
                             loc_end = min(base + chunk, n_work) - first;
                             // the lanes of the group walk the dependent loads of one item each, side by side
                             for (uint32_t i = gl; i < loc_end; i += GS) {
-                                const uint32_t gi = a.worklist[first + i];
+                                // wl_reverse: last entries first -- the coalescing kernels append the strands with the most
+                                // seed hits (long same-TaxId chains, long merged windows) last, and the longest items
+                                // should start first, not finish the launch alone
+                                const uint32_t gi = a.worklist[a.wl_reverse ? n_work - 1 - (first + i) : first + i];
                                 const uint4 c = a.cand[gi];
                                 const uint32_t rs = c.w;
                                 const uint32_t r_ = a.r0 + (rs >> 1);
@@ -1970,7 +1990,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
     }
     if (pend) {
         uint32_t base = 0;
-        if (gl == 0) base = atomicAdd(a.pass_count, pend);
+        if (gl == 0) base = atomicAdd(sw_pass_count(a), pend);
         base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
         wave_lds_handoff();
         for (uint32_t i = gl; i < pend; i += GS) a.pass_list[base + i] = pend_buf[i];
@@ -1982,9 +2002,9 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         s64 += __shfl_down(s64, d);
     }
     if (lane == 0 && v64) {
-        atomicAdd(a.n_verified, v64);
-        atomicAdd(a.window_bytes, w64);
-        if (s64) atomicAdd(a.sw_columns, s64 * R);  // cell pairs swept (one packed 7-instruction recurrence each)
+        atomicAdd((unsigned long long*)a.counters + kCtrVerified, v64);
+        atomicAdd((unsigned long long*)a.counters + kCtrWindowBytes, w64);
+        if (s64) atomicAdd((unsigned long long*)a.counters + kCtrSwCellPairs, s64 * R);  // cell pairs swept (one packed 7-instruction recurrence each)
     }
 }
 
@@ -2358,7 +2378,7 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     c.n_cand_total = n_cand_total;
     hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, c);
     // the list of longer strands is short (device-side count): a modest grid of wavefronts walks it
-    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 1024, 1), 256)), dim3(256), 0, s, ix, c);
+    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 1024)), dim3(256), 0, s, ix, c);
     HeavyArgs a;
     a.read_off = read_off;
     a.r0 = r0;

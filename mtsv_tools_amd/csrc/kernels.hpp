@@ -17,6 +17,9 @@ struct DevHit {  // byte-identical to mtsv_hit (include/mtsv_amd.h)
 };
 static_assert(sizeof(DevHit) == 32, "DevHit must match mtsv_hit");
 
+// slots of a lane's counter block (batch.hip: d_counters) that kernels address by number
+constexpr uint32_t kCtrVerified = 4, kCtrWindowBytes = 5, kCtrSwCursor = 8, kCtrPassCount = 9, kCtrSwCellPairs = 14;
+
 struct EvalArgs {
     const uint8_t* bases;
     const uint32_t* read_off;
@@ -30,6 +33,10 @@ struct EvalArgs {
     const uint32_t* worklist;     // candidate indices of this round
     const uint32_t* wl_count;
     uint32_t* wl_cursor;         // dynamic scheduling: next unclaimed worklist position
+    uint32_t wl_reverse = 0;     // k_sw_pairs: consume the worklist from its end
+    // k_sw_pairs: the lane's counter block (kCtr* slots below) and the slot whose low word holds its worklist length
+    uint64_t* counters = nullptr;
+    uint32_t wl_count_slot = 0;
     uint4* out;                   // out[candidate] = (tax_id, gi, offset, edit) when it passed
     unsigned long long* n_verified;
     unsigned long long* window_bytes;

@@ -231,7 +231,7 @@ def test_run_host_errors_surface_from_the_uploader(small_db):
     ix, _ = small_db
     ix.to_device(0)
     b = M.Batch(ix, 0, 64, 1 << 16)
-    reads = [b"ACGT" * 30] * 200 + [b"ACGT" * 150] + [b"ACGT" * 30] * 50   # a 600-base read in slice 3
+    reads = [b"ACGT" * 30] * 200 + [b"ACGT" * 10000] + [b"ACGT" * 30] * 50   # a 40000-base read in slice 3: beyond the tiled kernel's cells
     bases, off = helpers.reads_to_batch(reads)
     with pytest.raises(M.MtsvError) as e:
         b.run_host(bases, off)
