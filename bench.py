@@ -158,18 +158,28 @@ def main():
     hb.set_verify_mode(args.verify_mode)
     bases_p, off_p = bases.ctypes.data, off.ctypes.data
 
+    split = [0.0, 0.0, 0.0]  # seconds inside mtsv_batch_run_host / mtsv_batch_download / mtsv_hits_free over the timed steps
+
     def host_step(keep=False):
+        t_a = time.perf_counter()
         L._check(M.lib().mtsv_batch_run_host(hb.h, bases_p, off_p, n_reads, ctypes.byref(params)))
+        t_b = time.perf_counter()
         out_p, out_n = ctypes.c_void_p(), ctypes.c_uint64()
         L._check(M.lib().mtsv_batch_download(hb.h, ctypes.byref(out_p), ctypes.byref(out_n)))
+        t_c = time.perf_counter()
         if keep:
             return L._hits_from(out_p, out_n.value)  # copies, then frees
         M.lib().mtsv_hits_free(out_p)
+        t_d = time.perf_counter()
+        split[0] += t_b - t_a
+        split[1] += t_c - t_b
+        split[2] += t_d - t_c
         return None
 
     for _ in range(args.warmup):
         host_step()
     barrier()
+    split[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     host_stage = None
     for _ in range(args.steps):
@@ -357,6 +367,8 @@ def main():
         "value_region": "SURVEY 8(d): wall clock over host bases in -> host hits out through the C ABI (mtsv_batch_run_host + "
                         "mtsv_batch_download = mtsv_bin_batch on a warm workspace), H2D of reads and D2H of hits included; "
                         "index load/upload excluded",
+        "timed_calls_ms_per_step": {"mtsv_batch_run_host": split[0] / args.steps * 1e3, "mtsv_batch_download": split[1] / args.steps * 1e3,
+                                    "mtsv_hits_free": split[2] / args.steps * 1e3},
         "device_resident": resident,
         "config": {"workload": f"{args.workload}: {desc}", "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                    "index_symbols": info["n"], "index_file_bytes": os.path.getsize(idx_path),

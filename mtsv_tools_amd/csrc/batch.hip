@@ -413,10 +413,10 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         // counters: [1] lo = round-0 worklist count, [7] lo/hi = ping-pong counts of later rounds
         HIP_CHECK(hipMemsetAsync(d_counters + 1, 0, 8, stream));
         HIP_CHECK(hipMemsetAsync(d_counters + 7, 0, 8, stream));
+        HIP_CHECK(hipMemsetAsync(d_counters + 15, 0, 8, stream));  // [15] lo = strands of 17..64 seed hits
         launch_coalesce(stream, v, so, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, p.max_candidates, d_strand_off,
                         d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next,
-                        d_cand_status, d_strand_ncand, d_worklist, (uint32_t*)(d_counters + 1), d_heavy_list,
-                        (uint32_t*)(d_counters + 1) + 1, (unsigned long long*)(d_counters + 3));
+                        d_cand_status, d_strand_ncand, d_worklist, d_heavy_list, d_counters);
         HIP_CHECK(hipEventRecord(ev[5], stream));
         // ---- verify: rounds over the same-TaxId chains ----
         {
@@ -627,6 +627,7 @@ bool pinned_hits_release(void* p) { return p && pool().put(p); }
 // their way to the pinned result array at once, in slice order, on a third stream.  Nothing waits for a
 // whole batch: the steady state runs at max(kernels, staging, DMA).
 void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p, uint64_t read_base) {
+    const double t_entry = now_s();
     HIP_CHECK(hipSetDevice(di->device));
     std::vector<Batch*> ls{this};
     for (auto& l : extra) ls.push_back(l.get());
@@ -660,7 +661,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     uint64_t next_grant = 0;   // next slice to be given an input buffer
     std::vector<size_t> free_bufs;
     for (size_t b = 0; b < NB; b++) free_bufs.push_back(b);
-    uint64_t ramp_floor = 192 << 10;
+    uint64_t ramp_floor = 512 << 10;  // measured on config2: 192 Ki 136 M reads/s, 512 Ki 138, 1 Mi 120-125
     if (const char* e = getenv("MTSV_RAMP_FLOOR")) ramp_floor = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));
     uint64_t next_take = 0;    // next slice a lane takes
     uint64_t next_commit = 0;  // next slice whose hits go to the host
@@ -832,7 +833,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     end_run();
     HIP_CHECK(hipStreamSynchronize(copy_stream2));
     staged_valid = staged_hits == total_hits;
-    if (trace) fprintf(stderr, "[run_host] hits on the host at %.1f ms (%llu slices)\n", (now_s() - run_t0) * 1e3, (unsigned long long)slices.size());
+    if (trace) fprintf(stderr, "[run_host] hits on the host at %.1f ms (%llu slices); %.1f ms since the call began\n", (now_s() - run_t0) * 1e3, (unsigned long long)slices.size(), (now_s() - t_entry) * 1e3);
     if (!staged_valid) throw std::runtime_error("internal: run_host staged " + std::to_string(staged_hits) + " of " + std::to_string(total_hits) + " hits");
 }
 

@@ -569,7 +569,9 @@ __device__ inline void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST
 // candidates by (TaxId, rank)) run as a block-wide bitonic network on keys held in LDS.  Segments
 // that do not fit the LDS array fall back to one wavefront sorting in L2-resident scratch.
 // ---------------------------------------------------------------------------------------------
-constexpr uint32_t kHeavyKeys = 8192;  // 64 KiB of LDS
+constexpr uint32_t kHeavyKeys = 8192;  // 64 KiB of LDS: the workgroup-wide sorts of the largest strands
+constexpr uint32_t kHeavyKeysSmall = 2048;  // 16 KiB: most heavy strands (a few seeds of several hundred hits each) fit, and
+                                            // four times as many workgroups are resident per CU
 
 template <bool BLK>
 struct KeyMem {
@@ -779,16 +781,19 @@ __device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_
     km.sync();  // the key array is free for the next strand
 }
 
+// The heavy strands sit at the END of the strand list (entry list_len - 1 - h), the 17..64-hit ones at its front.
+// KEYS = kHeavyKeysSmall takes the strands of up to that many hits, KEYS = kHeavyKeys all longer ones.
+template <uint32_t KEYS>
 __global__ __launch_bounds__(256) void k_coalesce_heavy(DevIndexView ix, HeavyArgs a, const uint32_t* __restrict__ heavy_list,
-                                                        const uint32_t* __restrict__ heavy_count) {
-    __shared__ uint64_t lk[kHeavyKeys];
+                                                        uint32_t list_len, const uint32_t* __restrict__ heavy_count) {
+    __shared__ uint64_t lk[KEYS];
     __shared__ uint32_t sh_nc;
     const uint32_t n_heavy = *heavy_count;
     for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const uint32_t rs = heavy_list[h];
+        const uint32_t rs = heavy_list[list_len - 1 - h];
         const uint32_t nh = a.strand_off[rs + 1] - a.strand_off[rs];
-        if (nh <= (uint32_t)kWave) continue;  // k_coalesce_mid's
-        if (nh <= kHeavyKeys) {
+        if (KEYS == kHeavyKeysSmall ? nh > kHeavyKeysSmall : nh <= kHeavyKeysSmall) continue;  // the other instantiation's
+        if (nh <= KEYS) {
             coalesce_big<true>(ix, a, rs, KeyMem<true>{lk}, &sh_nc);
         } else {
             if (threadIdx.x < kWave) coalesce_big<false>(ix, a, rs, KeyMem<false>{a.hit_key + a.strand_off[rs]}, nullptr);
@@ -814,11 +819,14 @@ struct CoalesceArgs {
     uint32_t* cand_status;
     uint32_t* strand_ncand;
     uint32_t* worklist;
-    uint32_t* wl_count;
-    uint32_t* heavy_list;
-    uint32_t* heavy_count;
-    unsigned long long* n_cand_total;
+    uint32_t* heavy_list;   // n_strands entries: 17..64-hit strands from the front, longer ones from the back
+    uint64_t* counters;     // the lane's counter block: one pointer instead of four (this kernel sits at the SGPR limit)
 };
+// slots of the counter block (batch.hip's d_counters) the coalescing kernels use
+__device__ inline uint32_t* co_wl_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 1); }
+__device__ inline uint32_t* co_heavy_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 1) + 1; }
+__device__ inline uint32_t* co_mid_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 15); }
+__device__ inline unsigned long long* co_n_cand(const CoalesceArgs& a) { return reinterpret_cast<unsigned long long*>(a.counters + 3); }
 
 __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs a) {
     __shared__ uint32_t pend_all[256 / kWave][kWave];
@@ -836,7 +844,10 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
         uint32_t gnh = gvalid ? a.strand_off[grs + 1] - go : 0;
         const bool big = gnh > 16;
         if (big) {  // not this kernel's: its group idles through this pass
-            if (gl == 0) a.heavy_list[atomicAdd(a.heavy_count, 1u)] = grs;
+            if (gl == 0) {
+                if (gnh <= (uint32_t)kWave) a.heavy_list[atomicAdd(co_mid_count(a), 1u)] = grs;                    // front: k_coalesce_mid
+                else a.heavy_list[a.n_strands - 1 - atomicAdd(co_heavy_count(a), 1u)] = grs;  // back: k_coalesce_heavy
+            }
             gnh = 0;
         }
         uint32_t maxnh = gnh;
@@ -940,7 +951,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
             uint32_t m = __popcll(em);
             if (pend + m > kWave) {
                 uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(a.wl_count, pend);
+                if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
                 base = __builtin_amdgcn_readfirstlane(base);
                 wave_mem_sync();
                 if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
@@ -953,7 +964,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
     }
     if (pend) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.wl_count, pend);
+        if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
         base = __builtin_amdgcn_readfirstlane(base);
         wave_mem_sync();
         if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
@@ -963,10 +974,10 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
         ver_sum += __shfl_down(ver_sum, d);
         win_sum += __shfl_down(win_sum, d);
     }
-    if (lane == 0 && cand_sum) atomicAdd(a.n_cand_total, cand_sum);
+    if (lane == 0 && cand_sum) atomicAdd(co_n_cand(a), cand_sum);
     if (lane == 0 && ver_sum) {  // the counters sit side by side: n_candidates, n_verified, window_bytes
-        atomicAdd(a.n_cand_total + 1, ver_sum);
-        atomicAdd(a.n_cand_total + 2, win_sum);
+        atomicAdd(co_n_cand(a) + 1, ver_sum);
+        atomicAdd(co_n_cand(a) + 2, win_sum);
     }
 }
 
@@ -1036,8 +1047,8 @@ __device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndex
         for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d);
         if (lane == 0) {
             a.strand_ncand[rs] = 0;
-            atomicAdd(a.n_cand_total + 1, (unsigned long long)min(nc, a.maxc));
-            atomicAdd(a.n_cand_total + 2, wsum);
+            atomicAdd(co_n_cand(a) + 1, (unsigned long long)min(nc, a.maxc));
+            atomicAdd(co_n_cand(a) + 2, wsum);
         }
         return nc;
     }
@@ -1053,7 +1064,7 @@ __device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndex
         uint32_t m = __popcll(em);
         if (pend + m > kWave) {  // flush the buffered items with one atomic
             uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(a.wl_count, pend);
+            if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
             base = __builtin_amdgcn_readfirstlane(base);
             if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
             pend = 0;
@@ -1070,26 +1081,25 @@ __global__ __launch_bounds__(256) void k_coalesce_mid(DevIndexView ix, CoalesceA
     const uint32_t lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
-    const uint32_t n_list = *a.heavy_count;
+    const uint32_t n_list = *co_mid_count(a);
     uint32_t pend = 0;
     unsigned long long cand_sum = 0;
     for (uint32_t h = wave; h < n_list; h += n_waves) {
         const uint32_t rs = a.heavy_list[h];
         const uint32_t o = a.strand_off[rs];
         const uint32_t nh = __builtin_amdgcn_readfirstlane(a.strand_off[rs + 1] - o);
-        if (nh > kWave) continue;  // k_coalesce_heavy's
         const uint32_t nc = coalesce_mid_strand(ix, a, rs, o, nh, pend_buf, pend);  // writes strand_ncand
         if (lane == 0) cand_sum += nc;
     }
     if (pend) {
         uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(a.wl_count, pend);
+        if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
         base = __builtin_amdgcn_readfirstlane(base);
         wave_mem_sync();
         if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
     }
     for (int d = 32; d > 0; d >>= 1) cand_sum += __shfl_down(cand_sum, d);
-    if (lane == 0 && cand_sum) atomicAdd(a.n_cand_total, cand_sum);
+    if (lane == 0 && cand_sum) atomicAdd(co_n_cand(a), cand_sum);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2353,8 +2363,10 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                      double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
                      const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
                      uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_status,
-                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, uint32_t* heavy_list,
-                     uint32_t* heavy_count, unsigned long long* n_cand_total) {
+                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* heavy_list, uint64_t* counters) {
+    uint32_t* wl_count = reinterpret_cast<uint32_t*>(counters + 1);
+    uint32_t* heavy_count = wl_count + 1;
+    unsigned long long* n_cand_total = reinterpret_cast<unsigned long long*>(counters + 3);
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n_strands, 16), 256 * 8));  // 4 strands per wavefront pass
     CoalesceArgs c;
     c.read_off = read_off;
@@ -2372,10 +2384,8 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     c.cand_status = cand_status;
     c.strand_ncand = strand_ncand;
     c.worklist = worklist;
-    c.wl_count = wl_count;
     c.heavy_list = heavy_list;
-    c.heavy_count = heavy_count;
-    c.n_cand_total = n_cand_total;
+    c.counters = counters;
     hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, c);
     // the list of longer strands is short (device-side count): a modest grid of wavefronts walks it
     hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 1024)), dim3(256), 0, s, ix, c);
@@ -2399,8 +2409,9 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     a.wl_count = wl_count;
     a.n_cand_total = n_cand_total;
     // persistent workgroups over the (device-side) list of heavy strands; usually a few thousand at most
-    hipLaunchKernelGGL(k_coalesce_heavy, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 64, 1), 1024)), dim3(256), 0, s, ix, a,
-                       heavy_list, heavy_count);
+    const dim3 hgrid(std::min<uint32_t>(std::max<uint32_t>(n_strands / 64, 1), 2048));
+    hipLaunchKernelGGL(k_coalesce_heavy<kHeavyKeysSmall>, hgrid, dim3(256), 0, s, ix, a, heavy_list, n_strands, heavy_count);
+    hipLaunchKernelGGL(k_coalesce_heavy<kHeavyKeys>, dim3(std::min<uint32_t>(hgrid.x, 512)), dim3(256), 0, s, ix, a, heavy_list, n_strands, heavy_count);
 }
 
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len) {

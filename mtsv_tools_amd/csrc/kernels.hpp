@@ -80,8 +80,7 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
                      double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
                      const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
                      uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_status,
-                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* wl_count, uint32_t* heavy_list,
-                     uint32_t* heavy_count, unsigned long long* n_cand_total);
+                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* heavy_list, uint64_t* counters);
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len);
 // reads of kMaxRegisterReadLen + 1 .. kMaxReadLen bases: the same sweep in bands of 256 rows (a.strip / a.strip_len set:
 // tiled_groups(max_items, strip_len) strips of strip_len uint2 each, strip_len >= the pass's longest window)
