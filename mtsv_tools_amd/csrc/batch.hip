@@ -377,7 +377,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         launch_search(stream, v, sb, so, (uint32_t)r0, nr, max_ns, K, G, d_seed_lo, d_seed_cnt);
         HIP_CHECK(hipEventRecord(ev[1], stream));
         if (max_ns)
-            launch_thin(stream, sb, so, (uint32_t)r0, nr, p.edit_rate, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
+            launch_thin(stream, sb, so, (uint32_t)r0, nr, p.edit_rate, p.min_seed, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
                         d_seed_pre, d_strand_hits, d_strand_nseeds);
         else {
             HIP_CHECK(hipMemsetAsync(d_strand_hits, 0, (uint64_t)nstr * 4, stream));
@@ -414,7 +414,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         HIP_CHECK(hipMemsetAsync(d_counters + 1, 0, 8, stream));
         HIP_CHECK(hipMemsetAsync(d_counters + 7, 0, 8, stream));
         HIP_CHECK(hipMemsetAsync(d_counters + 15, 0, 8, stream));  // [15] lo = strands of 17..64 seed hits
-        launch_coalesce(stream, v, so, (uint32_t)r0, nstr, p.edit_rate, p.min_seed, p.max_candidates, d_strand_off,
+        launch_coalesce(stream, v, so, (uint32_t)r0, nstr, p.max_candidates, d_strand_off,
                         d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next,
                         d_cand_status, d_strand_ncand, d_worklist, d_heavy_list, d_counters);
         HIP_CHECK(hipEventRecord(ev[5], stream));

@@ -69,7 +69,7 @@ struct Batch {
 
     std::vector<uint32_t> h_read_off;
     uint32_t max_len = 0;
-    static constexpr int kCounters = 16;
+    static constexpr int kCounters = 24;
     bool sw_diag = true;   // k_sw_pairs tries the ungapped diagonal as a lower bound first (MTSV_SW_DIAG=0: off)
     bool sw_pairs = true;  // reference order for reads <= 253 bases: k_sw_pairs + k_edit_myers (MTSV_SW=packed: k_evaluate)
     int verify_mode = 0;  // 0 = reference order (SW + edit per candidate), 1 = edit first (MTSV_VERIFY_EDIT_FIRST)

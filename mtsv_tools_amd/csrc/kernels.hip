@@ -17,6 +17,7 @@
 //
 // All arithmetic is integer; positions are u32 (n < 2^32).  No MFMA: the path is rank queries and
 // small dynamic programs.
+#include <cstdlib>
 #include <stdexcept>
 
 #include "kernels.hpp"
@@ -79,13 +80,12 @@ __device__ inline uint32_t fast_code(uint32_t ch) {
 // packed as 3-bit codes in strand order, so the search loop itself issues only rank-block loads.
 constexpr uint32_t kMaxPackedSeed = 32;
 
-__global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* __restrict__ bases,
-                                                const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t n_reads,
-                                                uint32_t max_ns, uint32_t K, uint32_t G,
-                                                uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
-    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t total = (uint64_t)n_reads * 2 * max_ns;
-    if (slot >= total) return;
+// one seed slot with the general code: any seed size, with or without the k-mer table (also the path of the
+// seeds whose table part holds an N, which k_search_fast hands over)
+__device__ inline void search_slot(const DevIndexView& ix, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ read_off,
+                                   uint32_t r0, uint32_t max_ns, uint32_t K, uint32_t G, uint64_t slot,
+                                   uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
+
     uint32_t j = (uint32_t)(slot % max_ns);
     uint64_t rs = slot / max_ns;
     uint32_t strand = (uint32_t)(rs & 1);
@@ -210,6 +210,125 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
     seed_cnt[slot] = hi - lo;
 }
 
+__global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* __restrict__ bases,
+                                                const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t n_reads,
+                                                uint32_t max_ns, uint32_t K, uint32_t G,
+                                                uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
+    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    uint64_t total = (uint64_t)n_reads * 2 * max_ns;
+    if (slot >= total) return;
+    search_slot(ix, bases, read_off, r0, max_ns, K, G, slot, seed_lo, seed_cnt);
+}
+
+// The common case -- k-mer table of KK symbols resident, 16 <= K <= 24, at most 8 symbols left for the FM
+// steps, fewer than 2^32 slots -- without any data-dependent trip count: the table index comes straight from
+// the seed's code bytes (four codes of a dword squeezed to 8 bits; complementing is a bitwise NOT and the
+// reverse strand's byte order already is the table's), then exactly K - KK rank steps.  Seeds with an N in
+// the table part (about one in thirty; they walk up to K steps) are queued in LDS and run through the general
+// code afterwards, packed into the workgroup's first wavefront(s), so the long walks of a few lanes do not
+// hold every wavefront of the launch.  (A global list fed by one atomic per wavefront made the kernel
+// atomic-bound: ~9 ns per single-address atomic, 2.5 M wavefronts with such a seed on config2.)
+template <int KK>
+__global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint8_t* __restrict__ bases,
+                                                     const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t total,
+                                                     uint32_t max_ns, uint32_t K, uint32_t G,
+                                                     uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
+    __shared__ uint32_t slow_q[256];
+    __shared__ uint32_t slow_n;
+    if (threadIdx.x == 0) slow_n = 0;
+    __syncthreads();
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool in_range = slot < total;
+    const uint32_t rs = in_range ? slot / max_ns : 0, j = in_range ? slot - rs * max_ns : 0;
+    const uint32_t strand = rs & 1, r = r0 + (rs >> 1);
+    const uint32_t b0 = read_off[r], L = read_off[r + 1] - b0;
+    const bool live = in_range && j < n_seeds_of(L, K, G);
+    uint32_t lo = 0, hi = 0;
+    bool slow = false;
+    if (live) {
+        const uint32_t off = j * G;
+        const uint32_t s0 = b0 + (strand ? L - off - K : off);  // first byte of the seed's span in the read buffer
+        const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
+        // 16 code bytes that hold the table part: the span's last 16 (forward) or first 16 (reverse strand)
+        const uint32_t tp = strand ? s0 : s0 + K - 16;
+        const uint32_t tw = tp >> 2, tsh = tp & 3;
+        uint32_t d[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) d[k] = b32[tw + k];
+        uint32_t packed = 0, nbits = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], tsh);
+            nbits |= (w & 0x04040404u) >> 2 << k;  // byte q of dword k -> bit 8q + k: which of the 16 bytes is an N
+            w &= 0x03030303u;                      // (an N outside the table part must not spill into its neighbour's field)
+            const uint32_t t = (w | (w >> 6)) & 0x000f000fu;
+            packed |= ((t | (t >> 12)) & 0xffu) << (8 * k);  // byte i of the 16 at bits [2i, 2i+2)
+        }
+        // the KK bytes that count: the last KK of the 16 (forward), the first KK (reverse)
+        uint32_t used = 0;  // bit 8q + k set when byte 4k + q is one of them
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const bool in = i >= 16 - KK;  // forward strand; mirrored below for the reverse strand
+            if (in) used |= 1u << (8 * (i & 3) + (i >> 2));
+        }
+        uint32_t used_rev = 0;
+#pragma unroll
+        for (int i = 0; i < KK; i++) used_rev |= 1u << (8 * (i & 3) + (i >> 2));
+        slow = (nbits & (strand ? used_rev : used)) != 0;
+        if (!slow) {
+            uint32_t idx;
+            if (strand) {
+                idx = ~packed;  // complement; byte 0 is the seed's last symbol: lowest bits, as the table wants
+            } else {
+                const uint32_t rv = __builtin_bitreverse32(packed);  // field order reversed, bits inside a field swapped
+                idx = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
+            }
+            if (KK < 16) idx &= (1u << (2 * KK)) - 1u;
+            const uint2 iv = ix.kmer_tab[idx];
+            lo = iv.x;
+            hi = iv.y;
+            // the K - KK symbols in front of the table part, eight bytes at most
+            const uint32_t fp = strand ? s0 + KK : s0;
+            const uint32_t fw = fp >> 2, fsh = fp & 3;
+            const uint32_t f0 = b32[fw], f1 = b32[fw + 1], f2 = b32[fw + 2];
+            const uint64_t fm = ((uint64_t)__builtin_amdgcn_alignbyte(f2, f1, fsh) << 32) | __builtin_amdgcn_alignbyte(f1, f0, fsh);
+            for (int i = (int)K - KK - 1; i >= 0; i--) {  // wave-uniform trip count
+                // strand-order symbol i: span byte i (forward) or the complement of span byte K-1-i (reverse)
+                uint32_t a = (uint32_t)(fm >> (8 * (strand ? (int)K - 1 - i - KK : i))) & 0xffu;
+                if (strand) a = comp_code(a);
+                if (lo < hi) {
+                    const uint32_t bl = lo >> kBlockShift, bh = hi >> kBlockShift;
+                    const LoadedBlock B0 = load_block(ix.blocks, bl);
+                    const uint32_t nlo = less_of(ix, a) + block_rank(B0, a, bl, lo & (kBlockRows - 1), ix.sentinel_row);
+                    uint32_t nhi;
+                    if (bh == bl) {
+                        nhi = less_of(ix, a) + block_rank(B0, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
+                    } else {
+                        const LoadedBlock B1 = load_block(ix.blocks, bh);
+                        nhi = less_of(ix, a) + block_rank(B1, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
+                    }
+                    lo = nlo;
+                    hi = nhi;
+                }
+            }
+            if (lo >= hi) lo = hi = 0;  // Partial / Absent: only Complete intervals count (index.rs:312-332)
+        }
+    }
+    if (in_range && !slow) {
+        seed_lo[slot] = lo;
+        seed_cnt[slot] = hi - lo;
+    }
+    const unsigned long long sb = __ballot(slow);
+    if (sb) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(&slow_n, (uint32_t)__popcll(sb));
+        base = __builtin_amdgcn_readfirstlane(base);
+        if (slow) slow_q[base + __popcll(sb & ((1ull << lane_id()) - 1))] = slot;
+    }
+    __syncthreads();
+    if (threadIdx.x < slow_n) search_slot(ix, bases, read_off, r0, max_ns, K, G, slow_q[threadIdx.x], seed_lo, seed_cnt);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1b: sequential seed policy of one strand (index.rs:293-344,354)
 // ---------------------------------------------------------------------------------------------
@@ -222,7 +341,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
 constexpr uint32_t kHopeless = 0x80000000u;
 
 __global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ read_off,
-                                              uint32_t r0, uint32_t n_reads, double edit_rate,
+                                              uint32_t r0, uint32_t n_reads, double edit_rate, double min_seed,
                                               uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits,
                                               uint64_t tune_max_hits, uint32_t* __restrict__ seed_cnt,
                                               uint32_t* __restrict__ seed_pre, uint32_t* __restrict__ strand_hits,
@@ -287,7 +406,11 @@ __global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases,
         const uint32_t from_even = (uint32_t)__shfl_xor((int)nn, 1);  // every lane takes part in the exchange
         if (rs & 1) nn = from_even;                                     // odd lane: its read's count from the even lane
         hopeless = hopeless || nn > ED;
-        if (need && hopeless) nseeds |= kHopeless;
+        // what the coalescing kernels need of this strand, in one word: min_seeds = max(1, floor(n_seeds * pct))
+        // (index.rs:358; saturated at 16 bits, above any candidate's seed count), the edit tolerance, the flag
+        const double ms = floor((double)nseeds * min_seed);
+        const uint32_t min_seeds = ms < 1.0 ? 1u : (ms > 65535.0 ? 65535u : (uint32_t)ms);
+        nseeds = min_seeds | (ED << 16) | ((need && hopeless) ? kHopeless : 0u);
     }
     strand_hits[rs] = total;
     strand_nseeds[rs] = nseeds;
@@ -538,14 +661,12 @@ __device__ inline int row_sum16(int v) {
     return v;
 }
 
-__device__ inline StrandGeom strand_geom(const uint32_t* read_off, uint32_t r, double edit_rate, double min_seed,
-                                         uint32_t nseeds) {
+// geo = k_thin's word for the strand: min_seeds (16 bits) | ED << 16 | hopeless flag
+__device__ inline StrandGeom strand_geom(const uint32_t* read_off, uint32_t r, uint32_t geo) {
     StrandGeom g;
-    nseeds &= ~kHopeless;  // the top bit is k_thin's flag
     g.L = read_off[r + 1] - read_off[r];
-    g.ED = (uint32_t)ceil((double)g.L * edit_rate);           // index.rs:281-282
-    double ms = floor((double)nseeds * min_seed);             // index.rs:358
-    g.min_seeds = ms < 1.0 ? 1u : (ms > 4294967295.0 ? 0xffffffffu : (uint32_t)ms);
+    g.ED = (geo >> 16) & 0x7fffu;
+    g.min_seeds = geo & 0xffffu;
     return g;
 }
 
@@ -629,7 +750,6 @@ __device__ void big_sort(KeyMem<BLK> km, uint32_t n) {
 struct HeavyArgs {
     const uint32_t* read_off;
     uint32_t r0;
-    double edit_rate, min_seed;
     uint32_t maxc;
     const uint32_t* strand_off;
     const uint32_t* strand_nseeds;
@@ -656,7 +776,7 @@ __device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_
     const uint32_t nh = a.strand_off[rs + 1] - o;
     const uint32_t ns_raw = a.strand_nseeds[rs];
     const bool hopeless = (ns_raw & kHopeless) != 0;  // see k_coalesce
-    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, ns_raw);
+    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), ns_raw);
     for (uint32_t i = tid; i < nh; i += nt) km.st(i, ((uint64_t)a.hit_ref[o + i] << 32) | a.hit_q[o + i]);
     km.sync();
     big_sort(km, nh);  // seed_hits.sort(), index.rs:443
@@ -808,7 +928,6 @@ __global__ __launch_bounds__(256) void k_coalesce_heavy(DevIndexView ix, HeavyAr
 struct CoalesceArgs {
     const uint32_t* read_off;
     uint32_t r0, n_strands;
-    double edit_rate, min_seed;
     uint32_t maxc;
     const uint32_t* strand_off;
     const uint32_t* strand_nseeds;
@@ -836,34 +955,61 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
     const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
     uint32_t pend = 0;  // work items buffered in pend_buf (wave-uniform)
     unsigned long long cand_sum = 0, ver_sum = 0, win_sum = 0;
-    for (uint32_t rs4 = wave * 4; rs4 < a.n_strands; rs4 += n_waves * 4) {
-        const uint32_t gl = lane & 15, gbase = lane & 48;
-        const uint32_t grs = rs4 + (lane >> 4);
-        const bool gvalid = grs < a.n_strands;
-        const uint32_t go = gvalid ? a.strand_off[grs] : 0;
-        uint32_t gnh = gvalid ? a.strand_off[grs + 1] - go : 0;
-        const bool big = gnh > 16;
-        if (big) {  // not this kernel's: its group idles through this pass
-            if (gl == 0) {
-                if (gnh <= (uint32_t)kWave) a.heavy_list[atomicAdd(co_mid_count(a), 1u)] = grs;                    // front: k_coalesce_mid
-                else a.heavy_list[a.n_strands - 1 - atomicAdd(co_heavy_count(a), 1u)] = grs;  // back: k_coalesce_heavy
+    // A wavefront takes 64 consecutive strands at a time, one per lane, sorts them into classes -- empty (more
+    // than half of all strands: the other strand of a read, reads without an origin), 1..16 seed hits, longer --
+    // and then works through the 1..16-hit ones only, four at a time (one 16-lane group each).
+    for (uint32_t base64 = wave * kWave; base64 < a.n_strands; base64 += n_waves * kWave) {
+      const uint32_t my_rs = base64 + lane;
+      const bool my_valid = my_rs < a.n_strands;
+      const uint32_t my_o = my_valid ? a.strand_off[my_rs] : 0;
+      const uint32_t my_nh = my_valid ? a.strand_off[my_rs + 1] - my_o : 0;
+      if (my_valid && my_nh == 0) a.strand_ncand[my_rs] = 0;
+      {
+          const bool mid = my_nh > 16 && my_nh <= (uint32_t)kWave, heavy = my_nh > (uint32_t)kWave;
+          const unsigned long long bm = __ballot(mid), bh = __ballot(heavy);
+          if (bm) {  // front of the list: k_coalesce_mid
+              uint32_t b = 0;
+              if (lane == 0) b = atomicAdd(co_mid_count(a), (uint32_t)__popcll(bm));
+              b = __builtin_amdgcn_readfirstlane(b);
+              if (mid) a.heavy_list[b + __popcll(bm & ((1ull << lane) - 1))] = my_rs;
+          }
+          if (bh) {  // back of the list: k_coalesce_heavy
+              uint32_t b = 0;
+              if (lane == 0) b = atomicAdd(co_heavy_count(a), (uint32_t)__popcll(bh));
+              b = __builtin_amdgcn_readfirstlane(b);
+              if (heavy) a.heavy_list[a.n_strands - 1 - (b + __popcll(bh & ((1ull << lane) - 1)))] = my_rs;
+          }
+      }
+      unsigned long long small = __ballot(my_nh >= 1 && my_nh <= 16);
+      while (small) {
+        // the next four strands of this class, one per group (lane number inside the 64; 64 = none left)
+        uint32_t src = 64;
+        {
+            unsigned long long m = small;
+#pragma unroll
+            for (uint32_t g4 = 0; g4 < 4; g4++) {
+                const uint32_t s_g = m ? (uint32_t)__ffsll((long long)m) - 1 : 64u;
+                if (m) m &= m - 1;
+                if ((lane >> 4) == g4) src = s_g;
             }
-            gnh = 0;
+            small = m;
         }
+        const uint32_t gl = lane & 15, gbase = lane & 48;
+        const bool gvalid = src < 64;
+        const uint32_t grs = base64 + src;
+        const uint32_t go = (uint32_t)__shfl((int)my_o, (int)(src & 63)), gnh_raw = (uint32_t)__shfl((int)my_nh, (int)(src & 63));
+        const uint32_t gnh = gvalid ? gnh_raw : 0;
+        const bool big = false;
         uint32_t maxnh = gnh;
         maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 16));
         maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 32));
         maxnh = __builtin_amdgcn_readfirstlane(maxnh);
-        if (maxnh == 0) {
-            if (gvalid && gl == 0 && !big) a.strand_ncand[grs] = 0;
-            continue;
-        }
         StrandGeom gg{0, 0, 1};
         bool hopeless = false;  // group-uniform: k_thin's flag (see kHopeless)
         if (gvalid && gnh) {
             const uint32_t ns_raw = a.strand_nseeds[grs];
             hopeless = (ns_raw & kHopeless) != 0;
-            gg = strand_geom(a.read_off, a.r0 + (grs >> 1), a.edit_rate, a.min_seed, ns_raw);
+            gg = strand_geom(a.read_off, a.r0 + (grs >> 1), ns_raw);
         }
         uint64_t key = gl < gnh ? ((uint64_t)a.hit_ref[go + gl] << 32) | a.hit_q[go + gl] : ~0ull;
         for (uint32_t k = 2; k <= 16; k <<= 1)  // bitonic sort inside the 16-lane group
@@ -961,6 +1107,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
             if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = go + rank;
             pend += m;
         }
+      }
     }
     if (pend) {
         uint32_t base = 0;
@@ -989,7 +1136,7 @@ __device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndex
     const uint32_t lane = lane_id();
     const uint32_t ns_raw = a.strand_nseeds[rs];
     const bool hopeless = (ns_raw & kHopeless) != 0;  // see k_coalesce
-    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), a.edit_rate, a.min_seed, ns_raw);
+    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), ns_raw);
     uint32_t nc = 0;
     // ---- registers only ----
     uint64_t key = lane < nh ? ((uint64_t)a.hit_ref[o + lane] << 32) | a.hit_q[o + lane] : ~0ull;
@@ -2323,15 +2470,31 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt) {
     uint64_t total = (uint64_t)n_reads * 2 * max_ns;
     if (!total) return;
-    hipLaunchKernelGGL(k_search, dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, n_reads, max_ns, K, G,
-                       seed_lo, seed_cnt);
+    const bool fast = ix.kmer_tab && total < 0xffffffffull && K >= 16 && K <= 24 && ix.kmer_k >= 12 && ix.kmer_k <= 16 &&
+                      K >= ix.kmer_k && K - ix.kmer_k <= 8 && !getenv("MTSV_SEARCH_GENERIC");
+    if (!fast) {
+        hipLaunchKernelGGL(k_search, dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, n_reads, max_ns, K, G,
+                           seed_lo, seed_cnt);
+        return;
+    }
+#define FAST_CASE(KKV)                                                                                                  \
+    hipLaunchKernelGGL((k_search_fast<KKV>), dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, (uint32_t)total, \
+                       max_ns, K, G, seed_lo, seed_cnt)
+    switch (ix.kmer_k) {
+    case 12: FAST_CASE(12); break;
+    case 13: FAST_CASE(13); break;
+    case 14: FAST_CASE(14); break;
+    case 15: FAST_CASE(15); break;
+    default: FAST_CASE(16); break;
+    }
+#undef FAST_CASE
 }
 
 void launch_thin(hipStream_t s, const uint8_t* bases, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, double edit_rate,
-                 uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre,
+                 double min_seed, uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre,
                  uint32_t* strand_hits, uint32_t* strand_nseeds) {
     hipLaunchKernelGGL(k_thin, dim3(cdiv((uint64_t)n_reads * 2, 256)), dim3(256), 0, s, bases, read_off, r0, n_reads, edit_rate,
-                       max_ns, K, G, max_hits, tune, seed_cnt, seed_pre, strand_hits, strand_nseeds);
+                       min_seed, max_ns, K, G, max_hits, tune, seed_cnt, seed_pre, strand_hits, strand_nseeds);
 }
 
 void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_sums, uint64_t* total, uint32_t* out) {
@@ -2360,7 +2523,7 @@ void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_ho
 }
 
 void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,
-                     double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
+                     int64_t max_candidates, const uint32_t* strand_off,
                      const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
                      uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_status,
                      uint32_t* strand_ncand, uint32_t* worklist, uint32_t* heavy_list, uint64_t* counters) {
@@ -2372,8 +2535,6 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     c.read_off = read_off;
     c.r0 = r0;
     c.n_strands = n_strands;
-    c.edit_rate = edit_rate;
-    c.min_seed = min_seed;
     c.maxc = rank_bound(max_candidates);
     c.strand_off = strand_off;
     c.strand_nseeds = strand_nseeds;
@@ -2392,8 +2553,6 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     HeavyArgs a;
     a.read_off = read_off;
     a.r0 = r0;
-    a.edit_rate = edit_rate;
-    a.min_seed = min_seed;
     a.maxc = rank_bound(max_candidates);
     a.strand_off = strand_off;
     a.strand_nseeds = strand_nseeds;

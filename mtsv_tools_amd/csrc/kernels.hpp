@@ -63,10 +63,11 @@ constexpr uint32_t kMaxReadLen = 32767;        // the tiled kernel's packed 16-b
 void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end);
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt);
-// bases / edit_rate: k_thin also flags the strands no candidate of which can be accepted (more N in the read than the edit
-// tolerance, or the usize wrap of index.rs:406); the flag travels in the top bit of strand_nseeds
+// strand_nseeds receives one word per strand for the coalescing kernels: min_seeds (index.rs:358) | edit tolerance << 16 |
+// a flag for the strands no candidate of which can be accepted (more N in the read than the edit tolerance, or the usize
+// wrap of index.rs:406)
 void launch_thin(hipStream_t s, const uint8_t* bases, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, double edit_rate,
-                 uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre,
+                 double min_seed, uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre,
                  uint32_t* strand_hits, uint32_t* strand_nseeds);
 // out has n+1 entries (out[n] = total); tile_sums needs scan_tiles(n) entries
 void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_sums, uint64_t* total, uint32_t* out);
@@ -77,7 +78,7 @@ void launch_expand(hipStream_t s, const DevIndexView& ix, uint32_t n_strands, ui
 void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_host, const uint32_t* total_hits_dev,
                    const uint32_t* hit_row, uint32_t* hit_ref, unsigned long long* lf_steps);
 void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,
-                     double edit_rate, double min_seed, int64_t max_candidates, const uint32_t* strand_off,
+                     int64_t max_candidates, const uint32_t* strand_off,
                      const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
                      uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_status,
                      uint32_t* strand_ncand, uint32_t* worklist, uint32_t* heavy_list, uint64_t* counters);

@@ -436,22 +436,31 @@ def medium():
     return ix, bases, off
 
 
-@pytest.mark.parametrize("k", ["16", "11"])
-def test_kmer_table_width_does_not_change_hits(tricky, monkeypatch, k):
+@pytest.mark.parametrize("k,extra", [("16", {}), ("15", {}), ("14", {}), ("13", {}), ("12", {}), ("11", {}),
+                                     ("16", dict(seed_size=24, seed_interval=11)), ("12", dict(seed_size=20)),
+                                     ("16", dict(seed_size=16, seed_interval=7)), ("13", dict(seed_size=22))])
+def test_kmer_table_width_does_not_change_hits(tricky, monkeypatch, k, extra):
     """The k-mer interval table replaces the first k backward-search steps of a seed; 16 is the widest
     (32 GiB, chosen by itself for the 10 GB index), and a table as wide as the seed minus two leaves two
-    FM steps.  Hits and counters must not depend on it."""
+    FM steps.  Hits and counters must not depend on it.  Widths 12..16 with seeds of 16..24 symbols take
+    k_search_fast (every instantiation here; seeds with an N in the table part go through k_search_slow),
+    everything else the general kernel."""
     entries, _, _ = helpers.tricky_db()
     ix2 = M.MGIndex.build(entries, threads=4)
     monkeypatch.setenv("MTSV_KMER_K", k)
     ix2.to_device(0)
     monkeypatch.delenv("MTSV_KMER_K")
     _, orc, reads = tricky
-    mp, op = both_params()
+    mp, op = both_params(**extra)
     bases, off = helpers.reads_to_batch(reads)
     want, ctr = orc.bin_batch(bases, off, op, threads=8)
     b = M.Batch(ix2, 0, len(reads), len(bases))
     b.upload(bases, off)
+    b.run(mp)
+    assert_same_hits(b.download(), want)
+    assert b.stats()["n_seed_hits"] == ctr["H"]
+    # the general kernel (every slot through the step-by-step search) agrees with the table-driven fast kernel
+    monkeypatch.setenv("MTSV_SEARCH_GENERIC", "1")
     b.run(mp)
     assert_same_hits(b.download(), want)
     assert b.stats()["n_seed_hits"] == ctr["H"]

@@ -7,6 +7,7 @@ rows.sort(key=lambda r:int(r["Start_Timestamp"]))
 passes=[];cur=None
 for r in rows:
     k=norm(r["Kernel_Name"])
+    k = "k_search" if k.startswith("k_search") else k
     if not k.startswith("k_") or k in ("k_expand_sa","k_kmer_level","k_kmer_level1"): continue
     d=(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e6
     if k=="k_search":
