@@ -64,6 +64,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the device-resident leg and the other verify order (profiling runs)")
+    ap.add_argument("--resident-only", action="store_true",
+                    help="profiling mode: upload the reads once and time K resident runs (mtsv_batch_run) only -- every launch in the "
+                         "process then belongs to a whole-batch pipeline pass (tools/profile_round.sh); the line is marked as such")
     ap.add_argument("--verify-mode", type=int, default=0, help="0: reference order (SW + edit per candidate), 1: edit first")
     ap.add_argument("--dev-flags", type=int, default=0, help="MTSV_DEV_* flags (1: sampled SA only, 2: no k-mer table)")
     args = ap.parse_args()
@@ -148,6 +151,28 @@ def main():
 
     def same_hits(a, b):
         return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in HIT_FIELDS)
+
+    if args.resident_only:
+        b = M.Batch(ix, local_rank, n_reads, len(bases))
+        b.set_verify_mode(args.verify_mode)
+        b.upload(bases, off)
+        for _ in range(args.warmup):
+            b.run(params)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            b.run(params)
+        barrier()
+        dt = time.perf_counter() - t0
+        st = b.stats()
+        print(json.dumps({"mode": "resident-only (profiling; not the benchmark line)", "metric": "reads/sec, reads resident in HBM",
+                          "value": n_reads * args.steps / dt, "unit": "reads/s", "ms_per_step": dt / args.steps * 1e3,
+                          "n_lanes": st.get("n_lanes", 1), "stage_ms": st["stage_ms"], "sw_prefilter_ms": st.get("sw_prefilter_ms"),
+                          "config": {"workload": f"{args.workload}: {desc}", "reads": n_reads, "verify_mode": args.verify_mode},
+                          "device_counters": {k: st[k] for k in ("n_seed_slots", "n_seed_hits", "n_candidates", "n_verified",
+                                                                  "window_bytes", "n_hits", "sw_cell_pairs")}}))
+        b.close()
+        return
 
     # ---- timed region = SURVEY 8(d): host bases in -> host hits out, through the C ABI ----
     # (mtsv_batch_run_host + mtsv_batch_download = what mtsv_bin_batch does on its cached workspace: the reads are

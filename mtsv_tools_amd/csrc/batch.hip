@@ -25,7 +25,11 @@ namespace {
 // memcpy / first-touch split over a few threads for large host buffers
 template <class F>
 void parallel_ranges(uint64_t n, F f) {
-    const int nt = n >= (32ull << 20) ? 4 : n >= (4ull << 20) ? 2 : 1;
+    static const int max_nt = [] {
+        const char* e = getenv("MTSV_COPY_THREADS");
+        return e ? std::max(1, std::min(16, atoi(e))) : 4;
+    }();
+    const int nt = std::min(max_nt, n >= (32ull << 20) ? 4 : n >= (4ull << 20) ? 2 : 1);
     if (nt == 1) return f(0, n);
     std::vector<std::thread> th;
     const uint64_t chunk = ((n + nt - 1) / nt + 4095) & ~4095ull;
@@ -661,7 +665,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     uint64_t next_grant = 0;   // next slice to be given an input buffer
     std::vector<size_t> free_bufs;
     for (size_t b = 0; b < NB; b++) free_bufs.push_back(b);
-    uint64_t ramp_floor = 512 << 10;  // measured on config2: 192 Ki 136 M reads/s, 512 Ki 138, 1 Mi 120-125
+    uint64_t ramp_floor = 256 << 10;  // measured on config2: 96 Ki .. 320 Ki within 1 %, 512 Ki 3 % slower, 1 Mi 15 % slower
     if (const char* e = getenv("MTSV_RAMP_FLOOR")) ramp_floor = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));
     uint64_t next_take = 0;    // next slice a lane takes
     uint64_t next_commit = 0;  // next slice whose hits go to the host
@@ -820,7 +824,9 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     std::vector<std::thread> th;
     const uint64_t n_lanes_used = n >= ls.size() * kLaneMinReads ? ls.size() : 1;
     lanes_used = n_lanes_used;
-    for (int t = 0; t < kUploaders; t++) th.emplace_back(uploader, t);
+    int n_up = kUploaders;
+    if (const char* e = getenv("MTSV_UPLOADERS")) n_up = std::max(1, std::min(kUploaders, atoi(e)));
+    for (int t = 0; t < n_up; t++) th.emplace_back(uploader, t);
     for (uint64_t i = 1; i < n_lanes_used; i++) th.emplace_back(lane_main, ls[i]);
     lane_main(this);
     for (auto& t : th) t.join();

@@ -1689,7 +1689,7 @@ __device__ inline int row_max16(int v) {
 }
 
 #ifndef MTSV_SW_OCC
-#define MTSV_SW_OCC 4
+#define MTSV_SW_OCC 3
 #endif
 constexpr int kSwOcc = MTSV_SW_OCC;  // resident workgroups of k_sw_pairs per CU
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs

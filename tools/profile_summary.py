@@ -13,10 +13,13 @@ import os
 import re
 import sys
 
+ROUND = os.environ.get("MTSV_PROFILE_ROUND", "r02")
+
 
 def norm(name):
     name = name.replace("void ", "").replace("mtsv::(anonymous namespace)::", "")
-    return re.sub(r"\(.*", "", name)
+    name = re.sub(r"\(.*", "", name)
+    return "k_search" if name.startswith("k_search") else name  # k_search_fast<KK> / k_search: one stage
 
 
 def find(d, suffix):
@@ -58,9 +61,13 @@ def pmc(dfetch, dwrite, workload, out, traffic):
         return sum(v["sum"] for k, v in per[kind].items()
                    if k.startswith("k_") and k not in ("k_expand_sa", "k_kmer_level", "k_kmer_level1")) * 1024 / passes
     fetch, write = pipeline("FETCH_SIZE_KB"), pipeline("WRITE_SIZE_KB")
+    def kernel_bytes(prefix):
+        f = sum(v["sum"] for k, v in per["FETCH_SIZE_KB"].items() if k.startswith(prefix))
+        w = sum(v["sum"] for k, v in per["WRITE_SIZE_KB"].items() if k.startswith(prefix))
+        return (f + w) * 1024 / passes
     summary = {
-        "workload": workload, "dev_flags": 0,
-        "source": f"{os.path.join('profiles', 'r01_' + workload + '_hbm_pmc.json')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `MTSV_LANES=1 bench.py --no-extras`; per-step = per-kernel sums / pipeline passes in the profiled process)",
+        "workload": workload, "dev_flags": 0, "k_sw_pairs_bytes_per_step": kernel_bytes("k_sw_pairs"),
+        "source": f"{os.path.join('profiles', ROUND + '_' + workload + '_hbm_pmc.json')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `MTSV_LANES=1 bench.py --resident-only`; per-step = per-kernel sums / pipeline passes in the profiled process)",
         "fetch_bytes_per_step_raw": fetch, "write_bytes_per_step": write, "hbm_bytes_per_step": fetch + write,
         "note": "FETCH_SIZE is in KiB and, per MI355X_MICROARCH.md, under-reports wide coalesced streams by 2x on gfx950; this path's 16-B-per-lane random gathers are uncalibrated, so the raw counter is quoted (with the 2x correction: fetch*2+write)",
         "hbm_bytes_per_step_with_2x_fetch_correction": 2 * fetch + write,
@@ -70,8 +77,36 @@ def pmc(dfetch, dwrite, workload, out, traffic):
     print(f"{passes} passes: fetch {fetch / 1e9:.1f} GB, write {write / 1e9:.1f} GB per step")
 
 
+def sq(dsq, dtrace, out):
+    """SQ counters per pipeline kernel (sums over its launches in the profiled process) next to its duration in the
+    same process' kernel trace; VALU rate = SQ_INSTS_VALU / 1024 SIMDs / duration."""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(find(dsq, "counter_collection.csv"))):
+        acc[norm(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    dur = collections.defaultdict(float)
+    for r in csv.DictReader(open(find(dsq, "kernel_trace.csv"))):
+        dur[norm(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    with open(out, "w") as f:
+        f.write("MTSV_LANES=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY "
+                "SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES\n  -- python3 bench.py --steps 1 --warmup 0 --resident-only     (one whole-batch pipeline pass; "
+                "sums over a kernel's launches; durations from the same profiled process)\n"
+                "VALU rate = SQ_INSTS_VALU / 1024 SIMDs / duration; issue ceiling of the chip ~540 wave-instr/us/SIMD (profiles/r01_valu_issue_rate.txt)\n")
+        for k in sorted(dur, key=lambda k: -dur[k]):
+            if not k.startswith("k_") or k in ("k_expand_sa", "k_kmer_level", "k_kmer_level1"):
+                continue
+            c = acc[k]
+            valu = c.get("SQ_INSTS_VALU", 0.0)
+            rate = valu / 1024 / (dur[k] * 1e3) if dur[k] else 0.0
+            wait = c.get("SQ_WAIT_INST_ANY", 0.0) / c["SQ_WAVE_CYCLES"] if c.get("SQ_WAVE_CYCLES") else float("nan")
+            f.write(f"{k:28s} {dur[k]:7.2f} ms  VALU {valu:.3g} ({rate:.0f}/us/SIMD)  SALU {c.get('SQ_INSTS_SALU', 0):.3g}  "
+                    f"LDS {c.get('SQ_INSTS_LDS', 0):.3g}  VMEM_RD {c.get('SQ_INSTS_VMEM_RD', 0):.3g}  SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES {wait:.2f}\n")
+    print("wrote", out)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "sq":
+        sq(sys.argv[2], sys.argv[3], sys.argv[4])
     else:
         pmc(*sys.argv[2:7])
