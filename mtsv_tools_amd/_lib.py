@@ -43,7 +43,7 @@ class BatchStats(C.Structure):  # mtsv_batch_stats
                 ("n_rounds", C.c_uint64), ("n_lanes", C.c_uint64), ("sw_cell_pairs", C.c_uint64), ("sw_prefilter_ms", C.c_float)]
 
     def as_dict(self):
-        d = {n: int(getattr(self, n)) for n, _ in self._fields_[1:]}
+        d = {n: (float(getattr(self, n)) if t is C.c_float else int(getattr(self, n))) for n, t in self._fields_[1:]}
         d["stage_ms"] = {STAGE_NAMES[i]: float(self.stage_ms[i]) for i in range(N_STAGES)}
         return d
 

@@ -469,7 +469,7 @@ def test_kmer_table_width_does_not_change_hits(tricky, monkeypatch, k, extra):
 
 
 @pytest.mark.parametrize("max_len", [60, 96, 128, 150, 200, 253])
-def test_prefilter_shortcuts_for_every_row_count(tricky, max_len):
+def test_prefilter_shortcuts_for_every_row_count(tricky, max_len, monkeypatch):
     """Every k_sw_pairs<R> instantiation (R is chosen from the longest read of the batch) with all three
     ways a candidate leaves the prefilter: decided on the seed diagonal without a sweep (substitutions
     only), passed or failed by the sweep (indels, junk), rejected by the N count.  Mixed lengths in one
@@ -503,6 +503,7 @@ def test_prefilter_shortcuts_for_every_row_count(tricky, max_len):
     assert len(want) > 300
     b = M.Batch(ix, 0, len(reads), len(bases))
     b.upload(bases, off)
+    swept = {}
     for mode in (0, 1, 0):
         b.set_verify_mode(mode)
         b.run(mp)
@@ -510,6 +511,19 @@ def test_prefilter_shortcuts_for_every_row_count(tricky, max_len):
         st = b.stats()
         if mode == 0:
             assert (st["n_verified"], st["window_bytes"]) == (ctr["n_sw"], ctr["W"])
+            swept["bounds"] = st["sw_cell_pairs"]
+    b.close()
+    # the instantiation without the lower bounds on the seed diagonal (every candidate that is not hopeless is
+    # swept) decides every candidate the same way: same hits, same counters, more cells
+    monkeypatch.setenv("MTSV_SW_DIAG", "0")
+    b = M.Batch(ix, 0, len(reads), len(bases))
+    monkeypatch.delenv("MTSV_SW_DIAG")
+    b.upload(bases, off)
+    b.run(mp)
+    assert_same_hits(b.download(), want)
+    st = b.stats()
+    assert (st["n_verified"], st["window_bytes"]) == (ctr["n_sw"], ctr["W"])
+    assert st["sw_cell_pairs"] > swept["bounds"]
     b.close()
 
 
