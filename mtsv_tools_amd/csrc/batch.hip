@@ -271,12 +271,32 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, con
                       uint32_t range_max_len, uint64_t read_base) {
     std::vector<Batch*> ls{this};
     for (auto& l : extra) ls.push_back(l.get());
-    // Chunks of at most ws_reads reads, handed to the lanes from a shared counter: after the first chunk the
-    // lanes drift apart, so one lane's index lookups run under another lane's prefilter.
+    // Chunks of at most ws_reads reads, handed to the lanes from a shared counter.  The lanes must not march in
+    // step (three index lookups at once, then three prefilters at once overlap nothing): every lane gets several
+    // chunks, and the first chunk of lane i is (i + 1) / lanes of a full one, so the lanes stay a fraction of a
+    // chunk apart and one lane's index lookups (gather-bound) run under another lane's prefilter (VALU-bound).
     uint64_t k = n >= ls.size() * kLaneMinReads ? ls.size() : 1;
-    const uint64_t n_chunks = std::max<uint64_t>(k, (n + ws_reads - 1) / ws_reads);
-    const uint64_t per = (n + n_chunks - 1) / n_chunks;
-    if (per > ws_reads) throw std::runtime_error("arg: range holds more reads than the workspace was created for");
+    uint64_t per_lane = 2;  // measured on config2: 1: 52.2 ms, 2: 51.9, 3: 53.0, 4: 54.7, 6: 57.0 per 10 M reads
+    if (const char* e = getenv("MTSV_CHUNKS_PER_LANE")) per_lane = std::max(1, atoi(e));
+    uint64_t n_chunks = std::max<uint64_t>(k, (n + ws_reads - 1) / ws_reads);
+    if (k > 1 && n >= k * per_lane * kLaneMinReads) n_chunks = std::max(n_chunks, k * per_lane);
+    std::vector<uint64_t> bound(n_chunks + 1, n);
+    bound[0] = 0;
+    if (k > 1 && n_chunks >= 2 * k) {
+        // sizes: per * 1/k, per * 2/k, .., per, then equal chunks of the rest
+        const double per0 = (double)n / ((double)n_chunks - (double)(k - 1) / 2.0);  // full chunk size with the short ones counted
+        uint64_t at = 0;
+        for (uint64_t c = 0; c < k; c++) {
+            at += (uint64_t)(per0 * (double)(c + 1) / (double)k);
+            bound[c + 1] = std::min(at, n);
+        }
+        const uint64_t rest = n - bound[k], m = n_chunks - k;
+        for (uint64_t c = 0; c < m; c++) bound[k + c + 1] = bound[k] + rest * (c + 1) / m;
+    } else {
+        for (uint64_t c = 0; c < n_chunks; c++) bound[c + 1] = n * (c + 1) / n_chunks;
+    }
+    for (uint64_t c = 0; c < n_chunks; c++)
+        if (bound[c + 1] - bound[c] > ws_reads) throw std::runtime_error("arg: range holds more reads than the workspace was created for");
     k = std::min(k, n_chunks);
     lanes_used = std::max<uint64_t>(lanes_used, k);
     std::vector<Segment> segs(n_chunks);
@@ -285,7 +305,7 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, con
         for (;;) {
             const uint64_t c = next.fetch_add(1);
             if (c >= n_chunks) return;
-            const uint64_t a = std::min(n, c * per), b = std::min(n, (c + 1) * per);
+            const uint64_t a = bound[c], b = bound[c + 1];
             const uint64_t before = lane->n_hits_total;
             // base normalisation (binner.rs:88-100) of this chunk's bytes: raw -> codes, on the lane's stream
             if (raw) launch_normalise(lane->stream, raw, sb, h_off[a], h_off[b]);
