@@ -104,6 +104,25 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # Host threads of a rank (uploaders, lanes, staging copies) stay on the NUMA node of their GPU: on a
+    # two-socket node eight ranks staging 25 GB/s each should not cross the socket interconnect.  Best effort.
+    affinity = None
+    try:
+        pr = torch.cuda.get_device_properties(local_rank)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+        if node >= 0 and os.environ.get("MTSV_BENCH_NO_AFFINITY") != "1":
+            cpus = set()
+            for part in open(f"/sys/devices/system/node/node{node}/cpulist").read().strip().split(","):
+                lo, _, hi = part.partition("-")
+                cpus.update(range(int(lo), int(hi or lo) + 1))
+            cpus &= set(os.sched_getaffinity(0))
+            if cpus:
+                os.sched_setaffinity(0, cpus)
+                affinity = f"NUMA node {node} of GPU {bdf} ({len(cpus)} CPUs)"
+    except Exception:
+        pass
+
     n_taxa, gis, seq_len, n_reads, read_len, desc = WORKLOADS[args.workload]
     if args.reads:
         n_reads = args.reads
@@ -398,6 +417,7 @@ def main():
         "config": {"workload": f"{args.workload}: {desc}", "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                    "index_symbols": info["n"], "index_file_bytes": os.path.getsize(idx_path),
                    "index_hbm_bytes": info["device_bytes"], "dev_flags": args.dev_flags, "workspace_reads": min(n_reads, slice_reads),
+                   "host_cpu_affinity": affinity,
                    "verify_mode": ["reference (SW prefilter + edit distance per verified candidate)", "edit_first"][args.verify_mode],
                    "parallelism": f"reads sharded x{world}, index replicated, no collective"},
         "roofline": roof,
