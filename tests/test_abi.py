@@ -53,6 +53,17 @@ def test_no_cpu_fallback(tmp_path):
     with pytest.raises(M.MtsvError) as e:
         ix.bin_batch(bases, off, device=-1)  # the survey's "-1 = CPU oracle" is deliberately not offered
     assert e.value.code == _lib.E_ARG
+    # the multi-GPU entry points fail the same way (every device thread's error reaches the caller)
+    with pytest.raises(M.MtsvError) as e:
+        M.bin_batch_multi(ix, [0, 1], bases, off)
+    assert e.value.code == _lib.E_DEVICE
+    with pytest.raises(M.MtsvError) as e:
+        M.bin_batch_chunks([ix, ix], [0, 0], bases, off)
+    assert e.value.code == _lib.E_DEVICE
+    with pytest.raises(M.MtsvError) as e:
+        M.bin_batch_multi(ix, [0, -1], bases, off)
+    assert e.value.code in (_lib.E_ARG, _lib.E_DEVICE)
+    assert M.bin_batch_slice_reads(10) == 1024 and M.bin_batch_slice_reads(10**9) == 3 << 20
 
 
 def test_format_results_equals_reference_vectors_and_oracle():

@@ -27,6 +27,12 @@ def test_exit_codes_without_touching_the_gpu(tmp_path):
     assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--output-format", "xml").returncode == 1
     assert run("--fasta", str(tmp_path / "missing.fa"), "-i", "y", "-m", str(tmp_path / "r")).returncode == 2
     assert "2.1.0" in run("--version").stdout
+    # the multi-GPU extras are validated before anything is opened
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--devices", "0,x").returncode == 1
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--devices", "").returncode == 1
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--batch-reads", "0").returncode == 1
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--batch-reads", "many").returncode == 1
+    assert run("--fasta", "x", "-i", "y", "-m", str(tmp_path / "r"), "--batch-reads", "-5").returncode == 1
 
 
 def _golden_inputs(tmp_path):
