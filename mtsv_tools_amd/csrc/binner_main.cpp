@@ -416,15 +416,22 @@ int main(int argc, char** argv) {
         uint64_t skipped = 0;
         auto full = [&] { return w->n() >= batch_reads || w->bases.size() >= (1ull << 30); };
         mtsv_ingest::ParallelFastx par;
-        bool serial_from_start = getenv("MTSV_SERIAL_INGEST") != nullptr || !par.open(input, fastq, host_threads, getenv("MTSV_INGEST_BLOCK") ? strtoull(getenv("MTSV_INGEST_BLOCK"), nullptr, 10) : (16ull << 20));
+        mtsv_ingest::GzFastx gzpar;  // gzip input: parallel inflate + the same block parsers (MTSV_SERIAL_GZIP=1: zlib's one stream)
+        bool use_gz = false;
+        const uint64_t ingest_block = getenv("MTSV_INGEST_BLOCK") ? strtoull(getenv("MTSV_INGEST_BLOCK"), nullptr, 10) : (16ull << 20);
+        bool serial_from_start = getenv("MTSV_SERIAL_INGEST") != nullptr || !par.open(input, fastq, host_threads, ingest_block);
+        if (serial_from_start && !getenv("MTSV_SERIAL_INGEST") && !getenv("MTSV_SERIAL_GZIP") && gzpar.open(input, fastq, host_threads, ingest_block)) {
+            use_gz = true;
+            serial_from_start = false;
+        }
         if (!serial_from_start) {
             ReadBlock blk;
             uint64_t irregular = 0;
             for (;;) {
-                auto r = par.next(blk, &irregular);
+                auto r = use_gz ? gzpar.next(blk, &irregular) : par.next(blk, &irregular);
                 if (r == mtsv_ingest::ParallelFastx::END) break;
                 if (r == mtsv_ingest::ParallelFastx::IRREGULAR) {
-                    logmsg("DEBUG", "input is not plain 4-line FASTQ / FASTA at byte " + std::to_string(irregular) + "; continuing with the serial reader");
+                    logmsg("DEBUG", std::string(use_gz ? "gzip input" : "input") + " is not plain 4-line FASTQ / FASTA (or not decodable in parallel) at byte " + std::to_string(irregular) + "; continuing with the serial reader");
                     if (gzseek(rd.in.f, (z_off_t)irregular, SEEK_SET) < 0) {
                         rd.fail("read error");
                         return false;
@@ -462,6 +469,7 @@ int main(int argc, char** argv) {
                 }
             }
             par.close();
+            gzpar.close();
             if (!serial_from_start) {
                 if (w->n() && !emit(std::move(w))) return true;
                 return true;

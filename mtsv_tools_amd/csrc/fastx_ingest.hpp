@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <condition_variable>
+#include <deque>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -25,6 +26,8 @@
 #include <string>
 #include <thread>
 #include <vector>
+
+#include "pgzip.hpp"
 
 namespace mtsv_ingest {
 
@@ -130,6 +133,41 @@ class ParallelFastx {
         data_ = nullptr;
         if (fd_ >= 0) ::close(fd_);
         fd_ = -1;
+    }
+
+    // ---- shared with GzFastx: strict block parsers and the record-boundary heuristic on a memory range ----
+    static bool parse_block(const uint8_t* d, uint64_t len, bool fastq, bool first, bool last, ReadBlock& b) {
+        return fastq ? parse_fastq(d, len, b) : parse_fasta(d, len, first, last, b);
+    }
+    // first record start at or after t inside d[0, size) (a hint only: blocks are validated by the strict parse)
+    static uint64_t find_boundary_in(const uint8_t* d, uint64_t size, bool fastq, uint64_t t) {
+        auto lend = [&](uint64_t s, uint64_t limit) {
+            const void* nl = memchr(d + s, '\n', limit - s);
+            return nl ? (uint64_t)((const uint8_t*)nl - d) : limit;
+        };
+        if (t == 0 || t >= size) return t >= size ? UINT64_MAX : 0;
+        const uint64_t scan_limit = std::min<uint64_t>(size, t + (4ull << 20));
+        uint64_t s = lend(t - 1, scan_limit) + 1;
+        if (!fastq) {
+            while (s < scan_limit) {
+                if (d[s] == '>') return s;
+                s = lend(s, scan_limit) + 1;
+            }
+            return UINT64_MAX;
+        }
+        while (s < scan_limit) {
+            if (d[s] == '@') {
+                uint64_t l1 = lend(s, size) + 1;
+                uint64_t l2 = l1 < size ? lend(l1, size) + 1 : size;
+                if (l2 < size && d[l2] == '+') {
+                    uint64_t l3 = lend(l2, size) + 1;
+                    uint64_t l4 = l3 < size ? lend(l3, size) + 1 : size;
+                    if (l4 < size && d[l4] == '@') return s;  // (a record cut off by the end of the range is no proof)
+                }
+            }
+            s = lend(s, scan_limit) + 1;
+        }
+        return UINT64_MAX;
     }
 
    private:
@@ -303,6 +341,182 @@ class ParallelFastx {
     uint64_t consumed_ = 0;
     bool stop_ = false;
     std::vector<std::thread> pool_;
+};
+
+// gzip input: parallel decompression (pgzip.hpp) feeding the same strict block parsers.  A producer thread
+// inflates the file round by round, cuts the text at record boundaries into blocks and hands them to a pool of
+// parser threads; next() returns the blocks in input order.  IRREGULAR carries the offset in the DECOMPRESSED
+// stream from which the caller's serial reader (zlib: gzseek) has to continue -- for a block the strict parse
+// rejects, and also when the parallel inflater gives up (the serial reader then reports what zlib thinks).
+class GzFastx {
+   public:
+    using Result = ParallelFastx::Result;
+    ~GzFastx() { close(); }
+
+    bool open(const std::string& path, bool fastq, unsigned threads, uint64_t block_bytes = 16ull << 20) {
+        fastq_ = fastq;
+        block_ = std::max<uint64_t>(block_bytes, 1);
+        threads_ = std::max(1u, threads);
+        uint64_t chunk = 4ull << 20;  // compressed bytes per inflater thread and round
+        if (const char* e = getenv("MTSV_PGZIP_CHUNK")) chunk = strtoull(e, nullptr, 10);
+        if (!gz_.open(path, threads_, chunk)) return false;
+        window_ = 2 * threads_ + 2;
+        producer_ = std::thread([this] { produce(); });
+        for (unsigned k = 0; k < threads_; k++) pool_.emplace_back([this] { worker(); });
+        return true;
+    }
+
+    Result next(ReadBlock& out, uint64_t* irregular_offset) {
+        std::unique_ptr<Task> t;
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            cv_.wait(lk, [&] { return done_.count(consumed_) != 0 || (produced_all_ && consumed_ >= n_tasks_); });
+            if (!done_.count(consumed_)) {
+                if (failed_at_ != UINT64_MAX) {  // the inflater gave up: everything before failed_at_ has been delivered
+                    *irregular_offset = failed_at_;
+                    lk.unlock();
+                    stop();
+                    return ParallelFastx::IRREGULAR;
+                }
+                return ParallelFastx::END;
+            }
+            t = std::move(done_[consumed_]);
+            done_.erase(consumed_);
+            consumed_++;
+        }
+        cv_.notify_all();
+        if (!t->ok) {
+            *irregular_offset = t->offset;
+            stop();
+            return ParallelFastx::IRREGULAR;
+        }
+        std::swap(out, t->block);
+        return ParallelFastx::BLOCK;
+    }
+
+    void close() {
+        stop();
+        gz_.close();
+    }
+
+   private:
+    struct Task {
+        std::vector<uint8_t> data;
+        uint64_t offset = 0;  // of data[0] in the decompressed stream
+        bool first = false, last = false, ok = true;
+        ReadBlock block;
+    };
+
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        if (producer_.joinable()) producer_.join();
+        for (auto& t : pool_)
+            if (t.joinable()) t.join();
+        pool_.clear();
+    }
+
+    // hand a block to the parsers (bounded number in flight); false when stopping
+    bool submit(std::vector<uint8_t>&& data, uint64_t offset, bool first, bool last) {
+        auto t = std::make_unique<Task>();
+        t->data = std::move(data);
+        t->offset = offset;
+        t->first = first;
+        t->last = last;
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return stop_ || n_tasks_ < consumed_ + window_; });
+        if (stop_) return false;
+        queue_.emplace_back(n_tasks_++, std::move(t));
+        lk.unlock();
+        cv_.notify_all();
+        return true;
+    }
+
+    void produce() {
+        std::vector<uint8_t> carry;
+        uint64_t carry_off = 0;  // decompressed offset of carry[0]
+        bool first = true;
+        std::vector<std::vector<uint8_t>> pieces;
+        auto finish = [&](uint64_t failed_at) {
+            std::lock_guard<std::mutex> lk(mu_);
+            failed_at_ = failed_at;
+            produced_all_ = true;
+            cv_.notify_all();
+        };
+        while (!gz_.at_end()) {
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (stop_) return finish(UINT64_MAX);
+            }
+            if (!gz_.next_round(pieces)) return finish(carry_off);  // nothing at or after carry_off has been handed out
+            for (auto& piece : pieces) {
+                std::vector<uint8_t> buf;
+                if (carry.empty()) buf = std::move(piece);
+                else {
+                    buf = std::move(carry);
+                    buf.insert(buf.end(), piece.begin(), piece.end());
+                    std::vector<uint8_t>().swap(piece);
+                }
+                carry.clear();
+                uint64_t pos = 0;
+                while (buf.size() - pos > block_) {
+                    const uint64_t b = ParallelFastx::find_boundary_in(buf.data(), buf.size(), fastq_, pos + block_);
+                    if (b == UINT64_MAX || b <= pos) break;
+                    if (!submit(std::vector<uint8_t>(buf.begin() + (ptrdiff_t)pos, buf.begin() + (ptrdiff_t)b), carry_off + pos, first, false)) return finish(UINT64_MAX);
+                    first = false;
+                    pos = b;
+                }
+                carry.assign(buf.begin() + (ptrdiff_t)pos, buf.end());
+                carry_off += pos;
+            }
+        }
+        if (!carry.empty() || first) {
+            if (!submit(std::move(carry), carry_off, first, true)) return finish(UINT64_MAX);
+        }
+        finish(UINT64_MAX);
+    }
+
+    void worker() {
+        for (;;) {
+            uint64_t idx;
+            std::unique_ptr<Task> t;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || !queue_.empty() || produced_all_; });
+                if (stop_) return;
+                if (queue_.empty()) {
+                    if (produced_all_) return;
+                    continue;
+                }
+                idx = queue_.front().first;
+                t = std::move(queue_.front().second);
+                queue_.pop_front();
+            }
+            t->ok = ParallelFastx::parse_block(t->data.data(), t->data.size(), fastq_, t->first, t->last, t->block);
+            std::vector<uint8_t>().swap(t->data);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                done_[idx] = std::move(t);
+            }
+            cv_.notify_all();
+        }
+    }
+
+    mtsv_pgzip::ParallelGunzip gz_;
+    bool fastq_ = true;
+    uint64_t block_ = 16 << 20, window_ = 4;
+    unsigned threads_ = 1;
+    std::thread producer_;
+    std::vector<std::thread> pool_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::deque<std::pair<uint64_t, std::unique_ptr<Task>>> queue_;
+    std::map<uint64_t, std::unique_ptr<Task>> done_;
+    uint64_t n_tasks_ = 0, consumed_ = 0, failed_at_ = UINT64_MAX;
+    bool produced_all_ = false, stop_ = false;
 };
 
 }  // namespace mtsv_ingest

@@ -127,11 +127,89 @@ def test_fasta_blocks_equal_serial(tmp_path):
     assert parse_only(bad, False, block=4)[0] == 12
 
 
-def test_gzip_input_uses_the_serial_reader(tmp_path):
+def _gz(path, text, level=6, members=1):
     import gzip
+    data = text.encode("latin-1")
+    step = (len(data) + members - 1) // members or 1
+    with open(path, "wb") as f:
+        for i in range(0, max(len(data), 1), step):
+            f.write(gzip.compress(data[i:i + step], level))
+
+
+def parse_gz(path, fastq, serial=False, chunk=None, block=None, threads=4):
+    env = dict(os.environ, MTSV_HOST_THREADS=str(threads))
+    if serial:
+        env["MTSV_SERIAL_GZIP"] = "1"
+    if chunk:
+        env["MTSV_PGZIP_CHUNK"] = str(chunk)
+    if block:
+        env["MTSV_INGEST_BLOCK"] = str(block)
+    r = subprocess.run([BIN, "--parse-only", "--fastq" if fastq else "--fasta", str(path)], env=env, capture_output=True, text=True, timeout=120)
+    last = r.stdout.strip().splitlines()[-1] if r.stdout.strip() else ""
+    return r.returncode, last
+
+
+def test_gzip_input_parallel_inflate_equals_the_serial_stream(tmp_path):
+    """binner.rs:21-33 opens .gz through one inflate stream; here the stream is inflated in parallel (pgzip.hpp:
+    entry points found by search, windows resolved afterwards, CRC-32 of every member checked) and must hand the
+    parsers exactly the bytes zlib would: compression levels, several members, small inflater chunks (many entry
+    points, blocks cut inside them), CRLF text, FASTA, tiny and empty files."""
     rng = random.Random(10)
-    text = fastq_text(rng, 200)
+    text = fastq_text(rng, 20000)                      # ~4.5 MB
     (tmp_path / "a.fq").write_text(text)
-    with gzip.open(tmp_path / "a.fq.gz", "wt") as f:
-        f.write(text)
-    assert parse_only(tmp_path / "a.fq.gz", True) == parse_only(tmp_path / "a.fq", True, serial=True)
+    want = parse_only(tmp_path / "a.fq", True, serial=True)
+    assert want[0] == 0 and want[1].startswith("records=20000 ")
+    for level, members in ((1, 1), (6, 1), (9, 1), (6, 5), (0, 1)):
+        p = tmp_path / f"a_{level}_{members}.fq.gz"
+        _gz(p, text, level, members)
+        assert parse_gz(p, True, serial=True) == want
+        for chunk, block, threads in ((None, None, 4), (65536, 100000, 6), (70000, 4096, 3), (200000, None, 1)):
+            assert parse_gz(p, True, chunk=chunk, block=block, threads=threads) == want, (level, members, chunk)
+    crlf = fastq_text(rng, 3000, crlf=True)
+    _gz(tmp_path / "crlf.fq.gz", crlf)
+    (tmp_path / "crlf.fq").write_text(crlf, newline="")
+    assert parse_gz(tmp_path / "crlf.fq.gz", True, chunk=65536, block=50000) == parse_only(tmp_path / "crlf.fq", True, serial=True)
+    for name, t in (("tiny.fq.gz", "@x\nACGT\n+\nIIII\n"), ("nonl.fq.gz", "@x\nACGT\n+\nIIII"), ("empty.fq.gz", "")):
+        _gz(tmp_path / name, t)
+        assert parse_gz(tmp_path / name, True) == parse_gz(tmp_path / name, True, serial=True)
+        assert parse_gz(tmp_path / name, True)[0] == 0
+    # FASTA
+    recs = []
+    for i in range(4000):
+        s = rand_seq(rng, rng.randint(0, 500))
+        recs.append(f">s{i} text\n" + "\n".join(s[k:k + 70] for k in range(0, len(s), 70)) + "\n")
+    fa = "".join(recs)
+    _gz(tmp_path / "a.fa.gz", fa, 6, 3)
+    (tmp_path / "a.fa").write_text(fa)
+    assert parse_gz(tmp_path / "a.fa.gz", False, chunk=65536, block=30000) == parse_only(tmp_path / "a.fa", False, serial=True)
+
+
+def test_gzip_input_irregular_and_corrupt_files(tmp_path):
+    """wrapped FASTQ inside a .gz falls back to the serial reader from the offset of the first block the strict
+    parse rejects; truncated or damaged gzip data ends like it does with the serial stream (exit 12)"""
+    rng = random.Random(11)
+    recs = []
+    for i in range(6000):
+        L = rng.randint(50, 150)
+        s, q = rand_seq(rng, L), "".join(rng.choice("@+IJ") for _ in range(L))
+        if i >= 3000:
+            s = "\n".join(s[k:k + 40] for k in range(0, L, 40))
+            q = "\n".join(q[k:k + 40] for k in range(0, L, 40))
+        recs.append(f"@w{i}\n{s}\n+w{i}\n{q}\n")
+    text = "".join(recs)
+    _gz(tmp_path / "w.fq.gz", text)
+    (tmp_path / "w.fq").write_text(text)
+    want = parse_only(tmp_path / "w.fq", True, serial=True)
+    assert want[0] == 0 and want[1].startswith("records=6000 ")
+    assert parse_gz(tmp_path / "w.fq.gz", True, chunk=65536, block=20000) == want
+    assert parse_gz(tmp_path / "w.fq.gz", True) == want
+    good = (tmp_path / "w.fq.gz").read_bytes()
+    (tmp_path / "trunc.fq.gz").write_bytes(good[: len(good) // 2])
+    bad = bytearray(good)
+    for k in range(len(bad) // 3, len(bad) // 3 + 40):
+        bad[k] ^= 0x5a
+    (tmp_path / "bad.fq.gz").write_bytes(bytes(bad))
+    for name in ("trunc.fq.gz", "bad.fq.gz"):
+        s = parse_gz(tmp_path / name, True, serial=True)
+        g = parse_gz(tmp_path / name, True, chunk=65536)
+        assert s[0] == 12 and g[0] == 12, (name, s, g)
