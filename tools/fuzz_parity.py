@@ -44,7 +44,7 @@ def one(it, rng, tmp):
             gi += 1
     rng.shuffle(entries)
     entries.sort(key=lambda e: e[0])          # bins must be grouped by ascending TaxId (index.rs:523-541)
-    max_len = rng.choice((40, 75, 100, 150, 151, 200, 250, 253, 300, 400))
+    max_len = rng.choice((40, 75, 100, 150, 151, 200, 250, 253, 256, 257, 300, 400, 600, 1200))  # > 256: passes of the tiled kernel
     texts = [e[2] for e in entries]
     reads = []
     n_reads = rng.randrange(200, 1500) * (90 if os.environ.get("FUZZ_BIG") else 1)  # FUZZ_BIG: batches that run as lanes
@@ -84,7 +84,13 @@ def one(it, rng, tmp):
     path = os.path.join(tmp, "f.idx")
     ix.write(path)
     orc = O.Index.read(path)
+    # a k-mer table of 12 or 13 symbols (far wider than these small databases would get) sends the seeds of 16..24
+    # symbols through k_search_fast and its in-workgroup queue for seeds with an N
+    kk = rng.choice((None, None, "12", "13"))
+    if kk:
+        os.environ["MTSV_KMER_K"] = kk
     ix.to_device(0, rng.choice((0, 0, 0, 1, 2, 3)))
+    os.environ.pop("MTSV_KMER_K", None)
     bases, off = helpers.reads_to_batch(reads)
     want, ctr = orc.bin_batch(bases, off, O.default_params(**over), threads=8)
     mp = M.default_params(**over)
