@@ -1,1253 +1,10 @@
-// kernels.hip -- the mtsv-binner hot path as gfx950 kernels.
-//
-// One batch of reads flows through staged kernels with worklists in HBM:
-//
-//   k_search    lane per (read, strand, seed): FMIndex::backward_search           index.rs:305
-//   k_thin      lane per strand: adaptive seed thinning / max_hits filter         index.rs:293-344,354
-//   scan        exclusive scan of per-strand seed-hit counts
-//   k_expand    lane per kept seed: its SA rows / text positions (Interval::occ)  index.rs:347-352
-//   k_locate    lane per seed hit with wavefront refill: SampledSuffixArray::get  index.rs:347
-//   k_coalesce  wavefront per strand: sort, coalesce_seed_sites, min_seeds, rank  index.rs:358-369,435-487
-//   k_sw_pairs  16-lane group per two candidates: the SW prefilter                index.rs:401-406, ssw.c:123-328
-//   k_edit_myers  lane per candidate that passed it: bit-vector edit distance     index.rs:407-410, align.rs:28-85
-//               (rounds follow the same-TaxId chains of the ordered loop)
-//   k_evaluate  reads of 254-512 bases: both in one sweep + sw_sse2_word          ssw.c:354-530
-//   k_resolve   lane per strand: cut-offs and rank order of the selection loop    index.rs:384-428
-//   scan + k_gather  compact per-strand hits into (read, strand, rank) order      binner.rs:128
-//
-// All arithmetic is integer; positions are u32 (n < 2^32).  No MFMA: the path is rank queries and
-// small dynamic programs.
-#include <cstdlib>
-#include <stdexcept>
-
-#include "kernels.hpp"
+// k_verify.hip -- SW prefilter, edit distance, selection loop, hit gather (index.rs:384-428, ssw.c, align.rs)
+// (one of the three kernel files of the hot path; the stage map is in kernels.hpp / DESIGN.md section 3)
+#include "kernels_common.hpp"
 
 namespace mtsv {
 
 namespace {
-
-constexpr int kWave = 64;
-
-__device__ inline uint32_t lane_id() { return threadIdx.x & (kWave - 1); }
-
-// ---------------------------------------------------------------------------------------------
-// strand access: symbol code of position p of strand `strand` of a read (binner.rs:88-100,115)
-// ---------------------------------------------------------------------------------------------
-// (the read buffer holds symbol codes: k_normalise has run over it)
-__device__ inline uint32_t strand_code(const uint8_t* __restrict__ read, uint32_t L, uint32_t strand, uint32_t p) {
-    return strand ? comp_code(read[L - 1 - p]) : (uint32_t)read[p];
-}
-
-__device__ inline uint32_t n_seeds_of(uint32_t L, uint32_t K, uint32_t G) {
-    // offsets 0, G, 2G, ... < L + 1 - K  (index.rs:284-286); L + 1 < K is trapped as "no seeds"
-    return (L >= K) ? (L - K) / G + 1 : 0;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K0: base normalisation of the worker closure (binner.rs:88-100), src -> dst (may be the same buffer):
-// A/a C/c G/g T/t -> codes 0..3, every other byte -> N (4).  16 bytes per lane.  Everything
-// downstream reads codes; the reverse complement (binner.rs:115) is applied where a strand is read.
-// ---------------------------------------------------------------------------------------------
-__device__ inline uint32_t fast_code(uint32_t ch);
-__global__ __launch_bounds__(256) void k_normalise(const uint8_t* src, uint8_t* dst, uint64_t n_bytes) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (i >= n_bytes) return;
-    uint4 v = *reinterpret_cast<const uint4*>(src + i);  // both buffers are 16-byte aligned here and have 64 bytes of slack
-    uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-        uint32_t o = 0;
-#pragma unroll
-        for (int q = 0; q < 4; q++) o |= fast_code((w[k] >> (8 * q)) & 0xffu) << (8 * q);
-        w[k] = o;
-    }
-    *reinterpret_cast<uint4*>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1: backward search, one lane per seed slot
-// ---------------------------------------------------------------------------------------------
-// symbol code of an ASCII byte without a table: A/a C/c G/g T/t -> 0..3, anything else -> N (4)
-__device__ inline uint32_t fast_code(uint32_t ch) {
-    uint32_t uc = ch & 0xDFu;
-    uint32_t x = (uc >> 1) & 3u;
-    uint32_t c = x ^ (x >> 1);  // A0 C1 G2 T3
-    bool acgt = uc == 'A' || uc == 'C' || uc == 'G' || uc == 'T';
-    return acgt ? c : kCodeN;
-}
-
-// Seeds of up to 32 symbols are fetched with aligned dword loads (the read buffer is padded) and
-// packed as 3-bit codes in strand order, so the search loop itself issues only rank-block loads.
-constexpr uint32_t kMaxPackedSeed = 32;
-
-// one seed slot with the general code: any seed size, with or without the k-mer table (also the path of the
-// seeds whose table part holds an N, which k_search_fast hands over)
-__device__ inline void search_slot(const DevIndexView& ix, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ read_off,
-                                   uint32_t r0, uint32_t max_ns, uint32_t K, uint32_t G, uint64_t slot,
-                                   uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
-
-    uint32_t j = (uint32_t)(slot % max_ns);
-    uint64_t rs = slot / max_ns;
-    uint32_t strand = (uint32_t)(rs & 1);
-    uint32_t r = r0 + (uint32_t)(rs >> 1);
-    uint32_t b0 = read_off[r], L = read_off[r + 1] - b0;
-    uint32_t ns = n_seeds_of(L, K, G);
-    uint32_t lo = 0, hi = 0;
-    if (j < ns) {
-        const uint8_t* read = bases + b0;
-        uint32_t off = j * G;
-        // packed codes: symbol i of the seed (strand order) at bits [3i, 3i+3) of c_lo (i < 21) / c_hi
-        uint64_t c_lo = 0, c_hi = 0;
-        const bool packed = K <= kMaxPackedSeed;
-        // forward strand: bytes [off, off+K); reverse strand: bytes [L-off-K, L-off) reversed + complemented
-        const uint32_t s0 = b0 + (strand ? L - off - K : off);
-        const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
-        const uint32_t w0 = s0 >> 2, sh = s0 & 3;
-        if (K <= 21) {
-            // up to 21 symbols fit one 64-bit word; four codes of a dword are squeezed to 12 bits with shifts
-            // (codes < 8), the reverse strand is complemented bytewise and turned round by one 64-bit bit
-            // reversal (after swapping bit 0 and bit 2 of every code, which the reversal swaps back)
-            uint32_t d[7];
-#pragma unroll
-            for (int k = 0; k < 7; k++) d[k] = (uint32_t)(4 * k) < K + 4 ? b32[w0 + k] : 0u;
-            uint64_t c = 0;
-#pragma unroll
-            for (int k = 0; k < 6; k++) {
-                uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
-                if (strand) {
-                    const uint32_t m = (~w >> 2) & 0x01010101u;  // codes below 4: x -> 3 - x = x ^ 3
-                    w ^= m | (m << 1);
-                    const uint32_t t = (w ^ (w >> 2)) & 0x01010101u;
-                    w ^= t | (t << 2);
-                }
-                const uint32_t x = (w | (w >> 5)) & 0x003f003fu;
-                const uint32_t p12 = (x | (x >> 10)) & 0xfffu;
-                if (12 * k < 64) c |= (uint64_t)p12 << (12 * k);
-            }
-            c &= (K < 21 ? (1ull << (3 * K)) : (1ull << 63)) - 1;
-            if (strand) {
-                const uint64_t rv = ((uint64_t)__builtin_bitreverse32((uint32_t)c) << 32) | __builtin_bitreverse32((uint32_t)(c >> 32));
-                c = rv >> (64 - 3 * K);
-            }
-            c_lo = c;
-        } else if (packed) {
-            uint32_t d[9];
-            const uint32_t nd = (K + 3) / 4;  // dwords that hold seed bytes (wave-uniform)
-#pragma unroll
-            for (int k = 0; k < 9; k++) d[k] = (uint32_t)k <= nd ? b32[w0 + k] : 0u;
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-                if ((uint32_t)k >= nd) break;
-                uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
-#pragma unroll
-                for (int q = 0; q < 4; q++) {
-                    const uint32_t bi = k * 4 + q;  // byte index inside the fetched span
-                    uint32_t code = (w >> (8 * q)) & 0xffu;  // already a code (k_normalise)
-                    if (strand) code = comp_code(code);
-                    const uint32_t pos = strand ? (K - 1 - bi) : bi;  // strand-order position of this byte
-                    if (bi < K) {
-                        if (pos < 21) c_lo |= (uint64_t)code << (3 * pos);
-                        else c_hi |= (uint64_t)code << (3 * (pos - 21));
-                    }
-                }
-            }
-        }
-        auto sym = [&](uint32_t i) -> uint32_t {
-            if (packed) return (uint32_t)((i < 21 ? c_lo >> (3 * i) : c_hi >> (3 * (i - 21))) & 7u);
-            return strand_code(read, L, strand, off + i);
-        };
-        lo = 0;
-        hi = ix.n;
-        int i = (int)K - 1;
-        // the seed's last kmer_k symbols in one gather when none of them is N
-        if (ix.kmer_tab && K >= ix.kmer_k) {
-            uint32_t idx = 0;
-            bool acgt = true;
-            if (K <= 21) {
-                const uint32_t kk = ix.kmer_k;  // <= 16
-                const uint64_t sub = c_lo >> (3 * (K - kk));  // the last kk symbols, first of them lowest
-                const uint32_t s_lo = (uint32_t)sub & 0x3fffffffu, s_hi = (uint32_t)(sub >> 30) & 0x3ffffu;
-                acgt = ((s_lo & 0x24924924u) | (s_hi & 0x24924u)) == 0;  // no code has bit 2 set: all of A C G T
-                uint32_t idx16 = 0;  // symbol t at bits [2(15-t), 2(15-t)+2): the table's order, first symbol highest
-#pragma unroll
-                for (int t = 0; t < 16; t++) {
-                    const uint32_t a = t < 10 ? (s_lo >> (3 * t)) & 3u : (s_hi >> (3 * (t - 10))) & 3u;
-                    idx16 |= a << (2 * (15 - t));
-                }
-                idx = kk >= 16 ? idx16 : idx16 >> (2 * (16 - kk));
-            } else {
-                for (uint32_t t = 0; t < ix.kmer_k; t++) {
-                    uint32_t a = sym(K - ix.kmer_k + t);
-                    acgt &= a < 4;
-                    idx = (idx << 2) | (a & 3);
-                }
-            }
-            if (acgt) {
-                uint2 iv = ix.kmer_tab[idx];
-                lo = iv.x;
-                hi = iv.y;
-                i = (int)K - 1 - (int)ix.kmer_k;
-            }
-        }
-        for (; i >= 0 && lo < hi; i--) {
-            uint32_t a = sym((uint32_t)i);
-            uint32_t bl = lo >> kBlockShift, bh = hi >> kBlockShift;
-            LoadedBlock B0 = load_block(ix.blocks, bl);
-            uint32_t nlo = less_of(ix, a) + block_rank(B0, a, bl, lo & (kBlockRows - 1), ix.sentinel_row);
-            uint32_t nhi;
-            if (bh == bl) {
-                nhi = less_of(ix, a) + block_rank(B0, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
-            } else {
-                LoadedBlock B1 = load_block(ix.blocks, bh);
-                nhi = less_of(ix, a) + block_rank(B1, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
-            }
-            lo = nlo;
-            hi = nhi;
-        }
-        if (lo >= hi) lo = hi = 0;  // Partial / Absent: only Complete intervals count (index.rs:312-332)
-    }
-    seed_lo[slot] = lo;
-    seed_cnt[slot] = hi - lo;
-}
-
-__global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* __restrict__ bases,
-                                                const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t n_reads,
-                                                uint32_t max_ns, uint32_t K, uint32_t G,
-                                                uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
-    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    uint64_t total = (uint64_t)n_reads * 2 * max_ns;
-    if (slot >= total) return;
-    search_slot(ix, bases, read_off, r0, max_ns, K, G, slot, seed_lo, seed_cnt);
-}
-
-// The common case -- k-mer table of KK symbols resident, 16 <= K <= 24, at most 8 symbols left for the FM
-// steps, fewer than 2^32 slots -- without any data-dependent trip count: the table index comes straight from
-// the seed's code bytes (four codes of a dword squeezed to 8 bits; complementing is a bitwise NOT and the
-// reverse strand's byte order already is the table's), then exactly K - KK rank steps.  Seeds with an N in
-// the table part (about one in thirty; they walk up to K steps) are queued in LDS and run through the general
-// code afterwards, packed into the workgroup's first wavefront(s), so the long walks of a few lanes do not
-// hold every wavefront of the launch.  (A global list fed by one atomic per wavefront made the kernel
-// atomic-bound: ~9 ns per single-address atomic, 2.5 M wavefronts with such a seed on config2.)
-template <int KK>
-__global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint8_t* __restrict__ bases,
-                                                     const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t total,
-                                                     uint32_t max_ns, uint32_t K, uint32_t G,
-                                                     uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
-    __shared__ uint32_t slow_q[256];
-    __shared__ uint32_t slow_n;
-    if (threadIdx.x == 0) slow_n = 0;
-    __syncthreads();
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
-    const bool in_range = slot < total;
-    const uint32_t rs = in_range ? slot / max_ns : 0, j = in_range ? slot - rs * max_ns : 0;
-    const uint32_t strand = rs & 1, r = r0 + (rs >> 1);
-    const uint32_t b0 = read_off[r], L = read_off[r + 1] - b0;
-    const bool live = in_range && j < n_seeds_of(L, K, G);
-    uint32_t lo = 0, hi = 0;
-    bool slow = false;
-    if (live) {
-        const uint32_t off = j * G;
-        const uint32_t s0 = b0 + (strand ? L - off - K : off);  // first byte of the seed's span in the read buffer
-        const uint32_t* b32 = reinterpret_cast<const uint32_t*>(bases);
-        // 16 code bytes that hold the table part: the span's last 16 (forward) or first 16 (reverse strand)
-        const uint32_t tp = strand ? s0 : s0 + K - 16;
-        const uint32_t tw = tp >> 2, tsh = tp & 3;
-        uint32_t d[5];
-#pragma unroll
-        for (int k = 0; k < 5; k++) d[k] = b32[tw + k];
-        uint32_t packed = 0, nbits = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            uint32_t w = __builtin_amdgcn_alignbyte(d[k + 1], d[k], tsh);
-            nbits |= (w & 0x04040404u) >> 2 << k;  // byte q of dword k -> bit 8q + k: which of the 16 bytes is an N
-            w &= 0x03030303u;                      // (an N outside the table part must not spill into its neighbour's field)
-            const uint32_t t = (w | (w >> 6)) & 0x000f000fu;
-            packed |= ((t | (t >> 12)) & 0xffu) << (8 * k);  // byte i of the 16 at bits [2i, 2i+2)
-        }
-        // the KK bytes that count: the last KK of the 16 (forward), the first KK (reverse)
-        uint32_t used = 0;  // bit 8q + k set when byte 4k + q is one of them
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const bool in = i >= 16 - KK;  // forward strand; mirrored below for the reverse strand
-            if (in) used |= 1u << (8 * (i & 3) + (i >> 2));
-        }
-        uint32_t used_rev = 0;
-#pragma unroll
-        for (int i = 0; i < KK; i++) used_rev |= 1u << (8 * (i & 3) + (i >> 2));
-        slow = (nbits & (strand ? used_rev : used)) != 0;
-        if (!slow) {
-            uint32_t idx;
-            if (strand) {
-                idx = ~packed;  // complement; byte 0 is the seed's last symbol: lowest bits, as the table wants
-            } else {
-                const uint32_t rv = __builtin_bitreverse32(packed);  // field order reversed, bits inside a field swapped
-                idx = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
-            }
-            if (KK < 16) idx &= (1u << (2 * KK)) - 1u;
-            const uint2 iv = ix.kmer_tab[idx];
-            lo = iv.x;
-            hi = iv.y;
-            // the K - KK symbols in front of the table part, eight bytes at most
-            const uint32_t fp = strand ? s0 + KK : s0;
-            const uint32_t fw = fp >> 2, fsh = fp & 3;
-            const uint32_t f0 = b32[fw], f1 = b32[fw + 1], f2 = b32[fw + 2];
-            const uint64_t fm = ((uint64_t)__builtin_amdgcn_alignbyte(f2, f1, fsh) << 32) | __builtin_amdgcn_alignbyte(f1, f0, fsh);
-            for (int i = (int)K - KK - 1; i >= 0; i--) {  // wave-uniform trip count
-                // strand-order symbol i: span byte i (forward) or the complement of span byte K-1-i (reverse)
-                uint32_t a = (uint32_t)(fm >> (8 * (strand ? (int)K - 1 - i - KK : i))) & 0xffu;
-                if (strand) a = comp_code(a);
-                if (lo < hi) {
-                    const uint32_t bl = lo >> kBlockShift, bh = hi >> kBlockShift;
-                    const LoadedBlock B0 = load_block(ix.blocks, bl);
-                    const uint32_t nlo = less_of(ix, a) + block_rank(B0, a, bl, lo & (kBlockRows - 1), ix.sentinel_row);
-                    uint32_t nhi;
-                    if (bh == bl) {
-                        nhi = less_of(ix, a) + block_rank(B0, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
-                    } else {
-                        const LoadedBlock B1 = load_block(ix.blocks, bh);
-                        nhi = less_of(ix, a) + block_rank(B1, a, bh, hi & (kBlockRows - 1), ix.sentinel_row);
-                    }
-                    lo = nlo;
-                    hi = nhi;
-                }
-            }
-            if (lo >= hi) lo = hi = 0;  // Partial / Absent: only Complete intervals count (index.rs:312-332)
-        }
-    }
-    if (in_range && !slow) {
-        seed_lo[slot] = lo;
-        seed_cnt[slot] = hi - lo;
-    }
-    const unsigned long long sb = __ballot(slow);
-    if (sb) {
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&slow_n, (uint32_t)__popcll(sb));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (slow) slow_q[base + __popcll(sb & ((1ull << lane_id()) - 1))] = slot;
-    }
-    __syncthreads();
-    if (threadIdx.x < slow_n) search_slot(ix, bases, read_off, r0, max_ns, K, G, slow_q[threadIdx.x], seed_lo, seed_cnt);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1b: sequential seed policy of one strand (index.rs:293-344,354)
-// ---------------------------------------------------------------------------------------------
-// A strand is HOPELESS when no candidate of it can be accepted whatever its window holds: the usize wrap of
-// index.rs:406 (2*ED > L: the threshold L - 2*ED wraps and no score reaches it), or more N in the read than
-// the edit tolerance (a read N never matches in the edit-distance recurrence, index.rs:272-279, so
-// edits >= #N > ED fails :410).  The reference still runs its prefilter on every candidate of such a strand;
-// here the coalescing kernels account that work (counters) and emit no work items for it.  The flag
-// travels in the top bit of strand_nseeds.
-constexpr uint32_t kHopeless = 0x80000000u;
-
-__global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases, const uint32_t* __restrict__ read_off,
-                                              uint32_t r0, uint32_t n_reads, double edit_rate, double min_seed,
-                                              uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits,
-                                              uint64_t tune_max_hits, uint32_t* __restrict__ seed_cnt,
-                                              uint32_t* __restrict__ seed_pre, uint32_t* __restrict__ strand_hits,
-                                              uint32_t* __restrict__ strand_nseeds) {
-    uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rs >= n_reads * 2) return;
-    uint32_t r = r0 + (rs >> 1);
-    const uint32_t b0 = read_off[r];
-    uint32_t L = read_off[r + 1] - b0;
-    uint32_t ns = n_seeds_of(L, K, G);
-    uint64_t next_offset = 0, seed_interval = G;
-    uint32_t total = 0, nseeds = 0;
-    uint32_t* cnt = seed_cnt + (uint64_t)rs * max_ns;
-    uint32_t* pre = seed_pre + (uint64_t)rs * max_ns;
-    for (uint32_t j = 0; j < ns; j++) {
-        uint64_t offset = (uint64_t)j * G;
-        uint32_t c = cnt[j];
-        pre[j] = total;  // hits of the strand's earlier kept seeds (k_expand's output offset)
-        if (offset < next_offset) {  // index.rs:300-302
-            if (c) cnt[j] = 0;
-            continue;
-        }
-        if (c == 0) continue;        // index.rs:330-332
-        if ((uint64_t)c > max_hits) {  // index.rs:335-337
-            cnt[j] = 0;
-            continue;
-        }
-        if ((uint64_t)c > tune_max_hits) {  // index.rs:338-344
-            seed_interval *= 2;
-            next_offset = offset + seed_interval;
-        }
-        total += c;
-        nseeds++;
-    }
-    {
-        // the two strands of a read sit in neighbouring lanes (rs even / odd): the even lane counts the read's N once
-        // for both, and only when one of them has seed hits (only such strands can have candidates)
-        const bool need = total != 0;
-        const bool pair_need = need || __shfl_xor((int)need, 1) != 0;
-        const uint32_t ED = (uint32_t)ceil((double)L * edit_rate);  // index.rs:281-282
-        bool hopeless = 2ull * ED > (uint64_t)L;
-        uint32_t nn = 0;
-        if (pair_need && !hopeless && !(rs & 1)) {
-            // codes are 0..4, N = 4: bit 2 of every byte; aligned 16-byte groups of the code buffer (padded past its end)
-            const uint4* b128 = reinterpret_cast<const uint4*>(bases);
-            const uint32_t q0 = b0 >> 4, q1 = (b0 + L + 15) >> 4;
-            for (uint32_t qi = q0; qi < q1; qi++) {
-                const uint4 v = b128[qi];
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t byte0 = qi * 16 + 4 * k;  // buffer position of this dword's first byte
-                    uint32_t m = (w[k] >> 2) & 0x01010101u;
-                    // bytes outside [b0, b0 + L) belong to the neighbouring reads
-                    const int lo = (int)b0 - (int)byte0, hi = (int)(b0 + L) - (int)byte0;  // valid bytes [lo, hi) of this dword
-                    if (lo > 0) m = lo >= 4 ? 0u : (m & (0xffffffffu << (8 * lo)));
-                    if (hi < 4) m = hi <= 0 ? 0u : (m & ((1u << (8 * hi)) - 1u));
-                    nn += __popc(m);
-                }
-            }
-        }
-        const uint32_t from_even = (uint32_t)__shfl_xor((int)nn, 1);  // every lane takes part in the exchange
-        if (rs & 1) nn = from_even;                                     // odd lane: its read's count from the even lane
-        hopeless = hopeless || nn > ED;
-        // what the coalescing kernels need of this strand, in one word: min_seeds = max(1, floor(n_seeds * pct))
-        // (index.rs:358; saturated at 16 bits, above any candidate's seed count), the edit tolerance, the flag
-        const double ms = floor((double)nseeds * min_seed);
-        const uint32_t min_seeds = ms < 1.0 ? 1u : (ms > 65535.0 ? 65535u : (uint32_t)ms);
-        nseeds = min_seeds | (ED << 16) | ((need && hopeless) ? kHopeless : 0u);
-    }
-    strand_hits[rs] = total;
-    strand_nseeds[rs] = nseeds;
-}
-
-// ---------------------------------------------------------------------------------------------
-// exclusive scan of u32 counts (block sums in u64 so the host can detect > 2^32 totals)
-// ---------------------------------------------------------------------------------------------
-constexpr int kScanThreads = 256;
-constexpr int kScanItems = 8;
-constexpr int kScanTile = kScanThreads * kScanItems;
-
-__device__ inline uint32_t wave_incl_scan(uint32_t v) {
-    for (int d = 1; d < kWave; d <<= 1) {
-        uint32_t o = __shfl_up(v, d);
-        if ((int)lane_id() >= d) v += o;
-    }
-    return v;
-}
-
-__global__ __launch_bounds__(kScanThreads) void k_scan_tile_sums(const uint32_t* __restrict__ in, uint32_t n,
-                                                                 uint64_t* __restrict__ tile_sums) {
-    __shared__ uint32_t ws[kScanThreads / kWave];
-    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t s = 0;
-    for (int i = 0; i < kScanItems; i++)
-        if (base + i < n) s += in[base + i];
-    for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d);
-    if (lane_id() == 0) ws[threadIdx.x / kWave] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint64_t t = 0;
-        for (int w = 0; w < kScanThreads / kWave; w++) t += ws[w];
-        tile_sums[blockIdx.x] = t;
-    }
-}
-
-// single block: exclusive scan of tile sums in place; writes the grand total to *total
-__global__ __launch_bounds__(1024) void k_scan_sums(uint64_t* __restrict__ tile_sums, uint32_t n_tiles,
-                                                    uint64_t* __restrict__ total) {
-    __shared__ uint64_t buf[1024];
-    __shared__ uint64_t carry;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (uint32_t base = 0; base < n_tiles; base += 1024) {
-        uint32_t i = base + threadIdx.x;
-        uint64_t v = i < n_tiles ? tile_sums[i] : 0;
-        buf[threadIdx.x] = v;
-        __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
-            uint64_t o = threadIdx.x >= (uint32_t)d ? buf[threadIdx.x - d] : 0;
-            __syncthreads();
-            buf[threadIdx.x] += o;
-            __syncthreads();
-        }
-        uint64_t incl = buf[threadIdx.x];
-        uint64_t c = carry;
-        if (i < n_tiles) tile_sums[i] = c + incl - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = c + incl;
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *total = carry;
-}
-
-// out[i] = exclusive prefix, out[n] = total
-__global__ __launch_bounds__(kScanThreads) void k_scan_apply(const uint32_t* __restrict__ in, uint32_t n,
-                                                             const uint64_t* __restrict__ tile_sums,
-                                                             const uint64_t* __restrict__ total,
-                                                             uint32_t* __restrict__ out) {
-    __shared__ uint32_t ws[kScanThreads / kWave];
-    uint32_t base = blockIdx.x * kScanTile + threadIdx.x * kScanItems;
-    uint32_t v[kScanItems];
-    uint32_t s = 0;
-    for (int i = 0; i < kScanItems; i++) {
-        v[i] = base + i < n ? in[base + i] : 0;
-        s += v[i];
-    }
-    uint32_t incl = wave_incl_scan(s);
-    if (lane_id() == kWave - 1) ws[threadIdx.x / kWave] = incl;
-    __syncthreads();
-    uint32_t wbase = 0;
-    for (uint32_t w = 0; w < threadIdx.x / kWave; w++) wbase += ws[w];
-    uint32_t run = (uint32_t)tile_sums[blockIdx.x] + wbase + incl - s;
-    for (int i = 0; i < kScanItems; i++) {
-        if (base + i < n) out[base + i] = run;
-        run += v[i];
-    }
-    if (blockIdx.x == 0 && threadIdx.x == 0) out[n] = (uint32_t)*total;
-}
-
-// ---------------------------------------------------------------------------------------------
-// K1c: expand kept seeds into SA rows (or straight into text positions with the full SA)
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_expand(DevIndexView ix, uint64_t n_slots, uint32_t max_ns, uint32_t G,
-                                                const uint32_t* __restrict__ seed_lo,
-                                                const uint32_t* __restrict__ seed_cnt,
-                                                const uint32_t* __restrict__ seed_pre,
-                                                const uint32_t* __restrict__ strand_off,
-                                                uint32_t* __restrict__ hit_row, uint32_t* __restrict__ hit_ref,
-                                                uint32_t* __restrict__ hit_q) {
-    uint64_t slot = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t c = slot < n_slots ? seed_cnt[slot] : 0;
-    uint32_t o = 0, l = 0, q = 0;
-    if (c) {
-        const uint32_t rs = (uint32_t)(slot / max_ns), j = (uint32_t)(slot % max_ns);
-        o = strand_off[rs] + seed_pre[slot];
-        l = seed_lo[slot];
-        q = j * G;
-    }
-    // seeds with few hits: the lane writes them itself; repeats (up to max_hits per seed) are spread over the
-    // wavefront, one seed after the other, so that no single lane walks thousands of entries
-    constexpr uint32_t kOwn = 16;
-    if (c && c <= kOwn) {
-        for (uint32_t i = 0; i < c; i++) {
-            if (ix.sa_full) hit_ref[o + i] = ix.sa_full[l + i];
-            else hit_row[o + i] = l + i;
-            hit_q[o + i] = q;
-        }
-    }
-    unsigned long long big = __ballot(c > kOwn);
-    const uint32_t lane = lane_id();
-    while (big) {
-        const int src = __ffsll((long long)big) - 1;
-        big &= big - 1;
-        const uint32_t cs = __builtin_amdgcn_readlane(c, src), os = __builtin_amdgcn_readlane(o, src);
-        const uint32_t ls = __builtin_amdgcn_readlane(l, src), qs = __builtin_amdgcn_readlane(q, src);
-        for (uint32_t i = lane; i < cs; i += kWave) {
-            if (ix.sa_full) hit_ref[os + i] = ix.sa_full[ls + i];
-            else hit_row[os + i] = ls + i;
-            hit_q[os + i] = qs;
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
-// K2: locate by LF-walk over the row-sampled SA; finished lanes pull the next hit of the
-// wavefront's chunk (ballot + prefix count) so the geometric walk lengths do not idle the wave
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kLocateChunk = 512;
-
-__global__ __launch_bounds__(256) void k_locate(DevIndexView ix, const uint32_t* __restrict__ total_hits,
-                                                const uint32_t* __restrict__ hit_row,
-                                                uint32_t* __restrict__ hit_ref, unsigned long long* __restrict__ lf_steps) {
-    const uint32_t total = *total_hits;
-    const uint32_t lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
-    unsigned long long my_steps = 0;
-    for (uint64_t cbase = (uint64_t)wave * kLocateChunk; cbase < total; cbase += (uint64_t)n_waves * kLocateChunk) {
-        uint32_t next = (uint32_t)cbase;
-        const uint32_t end = (uint32_t)min((uint64_t)total, cbase + kLocateChunk);
-        bool active = false;
-        uint32_t idx = 0, row = 0, steps = 0;
-        for (;;) {
-            unsigned long long need = __ballot(!active);
-            uint32_t take = next + __popcll(need & ((1ull << lane) - 1));
-            if (!active && take < end) {
-                idx = take;
-                row = hit_row[idx];
-                steps = 0;
-                active = true;
-            }
-            next += __popcll(need);
-            if (!__any(active)) break;
-            if (active) {
-                bool sampled = ix.sa_pow2_shift != 0xffffffffu ? (row & (ix.sa_s - 1)) == 0 : (row % ix.sa_s) == 0;
-                if (sampled) {
-                    uint32_t j = ix.sa_pow2_shift != 0xffffffffu ? row >> ix.sa_pow2_shift : row / ix.sa_s;
-                    hit_ref[idx] = ix.sa_sample[j] + steps;
-                    active = false;
-                } else {
-                    uint32_t blk = row >> kBlockShift, off = row & (kBlockRows - 1);
-                    LoadedBlock b = load_block(ix.blocks, blk);
-                    uint32_t c = block_code(b, off);
-                    if (c == kCodeSentinel) {  // extra_rows: this row is the suffix at text position 0
-                        hit_ref[idx] = steps;
-                        active = false;
-                    } else {
-                        row = less_of(ix, c) + block_rank(b, c, blk, off, ix.sentinel_row);
-                        steps++;
-                        my_steps++;
-                        if (steps > ix.n) {  // only a corrupt index can cycle without a sampled row
-                            hit_ref[idx] = 0;
-                            active = false;
-                        }
-                    }
-                }
-            }
-        }
-    }
-    for (int d = 32; d > 0; d >>= 1) my_steps += __shfl_down(my_steps, d);
-    if (lane == 0 && my_steps) atomicAdd(lf_steps, my_steps);
-}
-
-// ---------------------------------------------------------------------------------------------
-// K3: coalesce
-// ---------------------------------------------------------------------------------------------
-__device__ inline uint64_t wave_bitonic_sort(uint64_t key) {
-    const uint32_t lane = lane_id();
-    for (uint32_t k = 2; k <= kWave; k <<= 1)
-        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-            uint64_t other = __shfl_xor(key, j);
-            bool up = (lane & k) == 0;
-            bool lower = (lane & j) == 0;
-            key = (lower == up) ? min(key, other) : max(key, other);
-        }
-    return key;
-}
-
-// first bin whose end > site (the forward-only cursor of index.rs:455-458 on sorted hits): a coarse
-// table gives the first bin that can hold the site's bucket, then a short forward scan
-__device__ inline uint32_t find_bin(const DevIndexView& ix, uint32_t site) {
-    const uint32_t k = site >> ix.bin_lut_shift;
-    uint32_t lo = ix.bin_lut[k], hi = ix.bin_lut[k + 1];  // the answer lies in [lo, hi]; usually lo == hi
-    while (lo < hi) {
-        uint32_t mid = (lo + hi) >> 1;
-        if (ix.bin_end[mid] <= site)
-            lo = mid + 1;
-        else
-            hi = mid;
-    }
-    return lo;
-}
-
-// SeedHit::candidate_indices (index.rs:118-153); returns false for None
-__device__ inline bool candidate_window(uint32_t site, uint32_t q, const DevBin& bin, uint32_t L, uint32_t ED,
-                                        uint32_t* ws, uint32_t* we) {
-    uint32_t start_offset = q + ED;
-    uint32_t s = (start_offset > site || site - start_offset < bin.start) ? bin.start : site - start_offset;
-    uint64_t e64 = (uint64_t)site + (L - q) + ED;
-    uint32_t e = e64 > bin.end ? bin.end : (uint32_t)e64;
-    *ws = s;
-    *we = e;
-    return !(s > e || e - s < L - ED);
-}
-
-struct StrandGeom {
-    uint32_t L, ED, min_seeds;
-};
-
-// sum over the 16 lanes of a DPP row, result in every lane
-__device__ inline int row_sum16(int v) {
-    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, false);   // quad_perm [1,0,3,2]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, false);   // quad_perm [2,3,0,1]
-    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, false);  // row_half_mirror
-    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xf, 0xf, false);  // row_mirror
-    return v;
-}
-
-// geo = k_thin's word for the strand: min_seeds (16 bits) | ED << 16 | hopeless flag
-__device__ inline StrandGeom strand_geom(const uint32_t* read_off, uint32_t r, uint32_t geo) {
-    StrandGeom g;
-    g.L = read_off[r + 1] - read_off[r];
-    g.ED = (geo >> 16) & 0x7fffu;
-    g.min_seeds = geo & 0xffffu;
-    return g;
-}
-
-// running state of the coalescing walk (index.rs:445-485)
-struct Walk {
-    bool have;
-    uint32_t s, e, b, n;
-};
-
-__device__ inline uint64_t gload(const uint64_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline void gstore(uint64_t* p, uint64_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ inline void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
-
-// ---------------------------------------------------------------------------------------------
-// Strands with more than 64 seed hits (repeats, N-run flanks: up to seeds x max_hits).  One
-// workgroup per strand; the three sorts (hits by (ref, q); candidates by (num_seeds desc, order);
-// candidates by (TaxId, rank)) run as a block-wide bitonic network on keys held in LDS.  Segments
-// that do not fit the LDS array fall back to one wavefront sorting in L2-resident scratch.
-// ---------------------------------------------------------------------------------------------
-constexpr uint32_t kHeavyKeys = 8192;  // 64 KiB of LDS: the workgroup-wide sorts of the largest strands
-constexpr uint32_t kHeavyKeysSmall = 2048;  // 16 KiB: most heavy strands (a few seeds of several hundred hits each) fit, and
-                                            // four times as many workgroups are resident per CU
-
-template <bool BLK>
-struct KeyMem {
-    uint64_t* p;
-    __device__ uint64_t ld(uint32_t i) const { return BLK ? p[i] : gload(p + i); }
-    __device__ void st(uint32_t i, uint64_t v) const {
-        if (BLK) p[i] = v;
-        else gstore(p + i, v);
-    }
-    __device__ void sync() const {
-        if (BLK) __syncthreads();
-        else wave_mem_sync();
-    }
-    __device__ uint32_t tid() const { return BLK ? threadIdx.x : lane_id(); }
-    __device__ uint32_t nthreads() const { return BLK ? blockDim.x : (uint32_t)kWave; }
-};
-
-// flip/disperse bitonic network (every comparator ascending, so virtual +inf padding above n is inert)
-template <bool BLK>
-__device__ void big_sort(KeyMem<BLK> km, uint32_t n) {
-    const uint32_t tid = km.tid(), nt = km.nthreads();
-    uint32_t np2 = 1;
-    while (np2 < n) np2 <<= 1;
-    const uint32_t half = np2 >> 1;
-    for (uint32_t k = 2; k <= np2; k <<= 1) {
-        for (uint32_t i = tid; i < half; i += nt) {
-            uint32_t hk = k >> 1, blk = i / hk, pos = i % hk;
-            uint32_t a = blk * k + pos, b = blk * k + k - 1 - pos;
-            if (b < n) {
-                uint64_t x = km.ld(a), y = km.ld(b);
-                if (x > y) {
-                    km.st(a, y);
-                    km.st(b, x);
-                }
-            }
-        }
-        km.sync();
-        for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-            for (uint32_t i = tid; i < half; i += nt) {
-                uint32_t blk = i / j, pos = i % j;
-                uint32_t a = blk * 2 * j + pos, b = a + j;
-                if (b < n) {
-                    uint64_t x = km.ld(a), y = km.ld(b);
-                    if (x > y) {
-                        km.st(a, y);
-                        km.st(b, x);
-                    }
-                }
-            }
-            km.sync();
-        }
-    }
-}
-
-struct HeavyArgs {
-    const uint32_t* read_off;
-    uint32_t r0;
-    uint32_t maxc;
-    const uint32_t* strand_off;
-    const uint32_t* strand_nseeds;
-    const uint32_t* hit_ref;
-    const uint32_t* hit_q;
-    uint64_t* hit_key;
-    uint64_t* cand_tmp;
-    uint4* cand;
-    uint32_t* cand_next;
-    uint32_t* cand_status;
-    uint32_t* strand_ncand;
-    uint32_t* worklist;
-    uint32_t* wl_count;
-    unsigned long long* n_cand_total;
-};
-
-// BLK: called by every thread of the workgroup (contains barriers); !BLK: by one wavefront
-template <bool BLK>
-__device__ void coalesce_big(const DevIndexView& ix, const HeavyArgs& a, uint32_t rs, KeyMem<BLK> km, uint32_t* sh_nc) {
-    const uint32_t lane = lane_id();
-    const uint32_t tid = km.tid(), nt = km.nthreads();
-    const bool walker = !BLK || threadIdx.x < kWave;  // the sequential walk runs on one wavefront
-    const uint32_t o = a.strand_off[rs];
-    const uint32_t nh = a.strand_off[rs + 1] - o;
-    const uint32_t ns_raw = a.strand_nseeds[rs];
-    const bool hopeless = (ns_raw & kHopeless) != 0;  // see k_coalesce
-    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), ns_raw);
-    for (uint32_t i = tid; i < nh; i += nt) km.st(i, ((uint64_t)a.hit_ref[o + i] << 32) | a.hit_q[o + i]);
-    km.sync();
-    big_sort(km, nh);  // seed_hits.sort(), index.rs:443
-    uint32_t nc = 0;
-    uint64_t* ct = a.cand_tmp + 2ull * o;
-    if (walker) {
-        Walk w{false, 0, 0, 0, 0};
-        for (uint32_t base = 0; base < nh; base += kWave) {
-            uint32_t cntv = min((uint32_t)kWave, nh - base);
-            uint32_t b = 0, ws = 0, we = 0;
-            bool ok = false;
-            if (lane < cntv) {
-                uint64_t key = km.ld(base + lane);
-                uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-                b = min(find_bin(ix, site), ix.n_bins - 1);
-                DevBin bin = ix.bins[b];
-                ok = candidate_window(site, q, bin, g.L, g.ED, &ws, &we);
-            }
-            for (uint32_t i = 0; i < cntv; i++) {
-                uint32_t wsi = __builtin_amdgcn_readlane(ws, i), wei = __builtin_amdgcn_readlane(we, i);
-                uint32_t bi = __builtin_amdgcn_readlane(b, i);
-                bool oki = __builtin_amdgcn_readlane((uint32_t)ok, i) != 0;
-                bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
-                if (merge) {  // add_seed_hit, index.rs:216-229
-                    w.s = min(w.s, wsi);
-                    w.e = max(w.e, wei);
-                    w.n++;
-                } else {
-                    if (w.have && w.n >= g.min_seeds) {  // index.rs:467-469
-                        if (lane == 0) {
-                            gstore(ct + 2ull * nc, ((uint64_t)w.e << 32) | w.s);
-                            gstore(ct + 2ull * nc + 1, ((uint64_t)w.n << 32) | w.b);
-                        }
-                        nc++;
-                    }
-                    w.have = oki;
-                    w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
-                }
-            }
-        }
-        if (w.have && w.n >= g.min_seeds) {  // index.rs:481-485
-            if (lane == 0) {
-                gstore(ct + 2ull * nc, ((uint64_t)w.e << 32) | w.s);
-                gstore(ct + 2ull * nc + 1, ((uint64_t)w.n << 32) | w.b);
-            }
-            nc++;
-        }
-        if (BLK && threadIdx.x == 0) *sh_nc = nc;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    km.sync();
-    if (BLK) nc = *sh_nc;
-    if (hopeless && a.maxc >= nc) {
-        // every candidate is prefiltered by the reference and none can pass: account the work, skip the ranking
-        unsigned long long wsum = 0;
-        for (uint32_t i = tid; i < nc; i += nt) {
-            const uint64_t se = gload(ct + 2ull * i);
-            wsum += (uint32_t)(se >> 32) - (uint32_t)se;
-        }
-        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d);
-        if (lane == 0 && wsum) atomicAdd(a.n_cand_total + 2, wsum);
-        if (tid == 0) {
-            a.strand_ncand[rs] = 0;
-            if (nc) {
-                atomicAdd(a.n_cand_total, (unsigned long long)nc);
-                atomicAdd(a.n_cand_total + 1, (unsigned long long)nc);
-            }
-        }
-        km.sync();  // the key array is free for the next strand
-        return;
-    }
-    // rank: sort (num_seeds descending, walk order ascending) -- the stable sort of index.rs:369
-    for (uint32_t i = tid; i < nc; i += nt) {
-        uint32_t n_i = (uint32_t)(gload(ct + 2ull * i + 1) >> 32);
-        km.st(i, ((uint64_t)(0xffffffffu - n_i) << 32) | i);
-    }
-    km.sync();
-    big_sort(km, nc);
-    for (uint32_t base = 0; base < nc; base += nt) {  // every thread runs the same trip count (barrier below)
-        uint32_t i = base + tid;
-        uint64_t taxkey = 0;
-        if (i < nc) {
-            uint32_t src = (uint32_t)km.ld(i);
-            uint64_t se = gload(ct + 2ull * src), bn = gload(ct + 2ull * src + 1);
-            a.cand[o + i] = make_uint4((uint32_t)se, (uint32_t)(se >> 32), (uint32_t)bn, rs);
-            a.cand_status[o + i] = 0;
-            taxkey = ((uint64_t)ix.bins[(uint32_t)bn].tax_id << 32) | i;  // (TaxId, rank)
-            if (hopeless && i < a.maxc) {  // max_candidates < nc: only the first ranks are prefiltered
-                atomicAdd(a.n_cand_total + 1, 1ull);
-                atomicAdd(a.n_cand_total + 2, (unsigned long long)((uint32_t)(se >> 32) - (uint32_t)se));
-            }
-        }
-        km.sync();  // all reads of this tile's rank keys are done before they are overwritten
-        if (i < nc) km.st(i, taxkey);
-    }
-    km.sync();
-    big_sort(km, nc);
-    for (uint32_t base = (BLK ? (threadIdx.x / kWave) * kWave : 0); base < nc; base += nt) {
-        uint32_t p = base + lane;
-        bool emit = false;
-        uint32_t rk = 0;
-        if (p < nc) {
-            uint64_t k0 = km.ld(p);
-            uint64_t kn = p + 1 < nc ? km.ld(p + 1) : ~0ull;
-            uint64_t kp = p > 0 ? km.ld(p - 1) : ~0ull;
-            rk = (uint32_t)k0;
-            a.cand_next[o + rk] = (kn >> 32) == (k0 >> 32) ? (uint32_t)kn : 0xffffffffu;
-            emit = (p == 0 || (kp >> 32) != (k0 >> 32)) && rk < a.maxc && !hopeless;
-        }
-        unsigned long long em = __ballot(emit);
-        if (em) {
-            uint32_t b2 = 0;
-            if (lane == 0) b2 = atomicAdd(a.wl_count, (uint32_t)__popcll(em));
-            b2 = __builtin_amdgcn_readfirstlane(b2);
-            if (emit) a.worklist[b2 + __popcll(em & ((1ull << lane) - 1))] = o + rk;
-        }
-    }
-    if (tid == 0) {
-        a.strand_ncand[rs] = hopeless ? 0 : nc;
-        if (nc) atomicAdd(a.n_cand_total, (unsigned long long)nc);
-    }
-    km.sync();  // the key array is free for the next strand
-}
-
-// The heavy strands sit at the END of the strand list (entry list_len - 1 - h), the 17..64-hit ones at its front.
-// KEYS = kHeavyKeysSmall takes the strands of up to that many hits, KEYS = kHeavyKeys all longer ones.
-template <uint32_t KEYS>
-__global__ __launch_bounds__(256) void k_coalesce_heavy(DevIndexView ix, HeavyArgs a, const uint32_t* __restrict__ heavy_list,
-                                                        uint32_t list_len, const uint32_t* __restrict__ heavy_count) {
-    __shared__ uint64_t lk[KEYS];
-    __shared__ uint32_t sh_nc;
-    const uint32_t n_heavy = *heavy_count;
-    for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {
-        const uint32_t rs = heavy_list[list_len - 1 - h];
-        const uint32_t nh = a.strand_off[rs + 1] - a.strand_off[rs];
-        if (KEYS == kHeavyKeysSmall ? nh > kHeavyKeysSmall : nh <= kHeavyKeysSmall) continue;  // the other instantiation's
-        if (nh <= KEYS) {
-            coalesce_big<true>(ix, a, rs, KeyMem<true>{lk}, &sh_nc);
-        } else {
-            if (threadIdx.x < kWave) coalesce_big<false>(ix, a, rs, KeyMem<false>{a.hit_key + a.strand_off[rs]}, nullptr);
-            __syncthreads();
-        }
-    }
-}
-
-
-// Strands with at most 16 seed hits, four per wavefront (one 16-lane group each); longer ones go to the list
-// k_coalesce_mid (17..64 hits, a wavefront each) and k_coalesce_heavy (more) work off.
-struct CoalesceArgs {
-    const uint32_t* read_off;
-    uint32_t r0, n_strands;
-    uint32_t maxc;
-    const uint32_t* strand_off;
-    const uint32_t* strand_nseeds;
-    const uint32_t* hit_ref;
-    const uint32_t* hit_q;
-    uint4* cand;
-    uint32_t* cand_next;
-    uint32_t* cand_status;
-    uint32_t* strand_ncand;
-    uint32_t* worklist;
-    uint32_t* heavy_list;   // n_strands entries: 17..64-hit strands from the front, longer ones from the back
-    uint64_t* counters;     // the lane's counter block: one pointer instead of four (this kernel sits at the SGPR limit)
-};
-// slots of the counter block (batch.hip's d_counters) the coalescing kernels use
-__device__ inline uint32_t* co_wl_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 1); }
-__device__ inline uint32_t* co_heavy_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 1) + 1; }
-__device__ inline uint32_t* co_mid_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 15); }
-__device__ inline unsigned long long* co_n_cand(const CoalesceArgs& a) { return reinterpret_cast<unsigned long long*>(a.counters + 3); }
-
-__global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs a) {
-    __shared__ uint32_t pend_all[256 / kWave][kWave];
-    uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
-    const uint32_t lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
-    uint32_t pend = 0;  // work items buffered in pend_buf (wave-uniform)
-    unsigned long long cand_sum = 0, ver_sum = 0, win_sum = 0;
-    // A wavefront takes 64 consecutive strands at a time, one per lane, sorts them into classes -- empty (more
-    // than half of all strands: the other strand of a read, reads without an origin), 1..16 seed hits, longer --
-    // and then works through the 1..16-hit ones only, four at a time (one 16-lane group each).
-    for (uint32_t base64 = wave * kWave; base64 < a.n_strands; base64 += n_waves * kWave) {
-      const uint32_t my_rs = base64 + lane;
-      const bool my_valid = my_rs < a.n_strands;
-      const uint32_t my_o = my_valid ? a.strand_off[my_rs] : 0;
-      const uint32_t my_nh = my_valid ? a.strand_off[my_rs + 1] - my_o : 0;
-      if (my_valid && my_nh == 0) a.strand_ncand[my_rs] = 0;
-      {
-          const bool mid = my_nh > 16 && my_nh <= (uint32_t)kWave, heavy = my_nh > (uint32_t)kWave;
-          const unsigned long long bm = __ballot(mid), bh = __ballot(heavy);
-          if (bm) {  // front of the list: k_coalesce_mid
-              uint32_t b = 0;
-              if (lane == 0) b = atomicAdd(co_mid_count(a), (uint32_t)__popcll(bm));
-              b = __builtin_amdgcn_readfirstlane(b);
-              if (mid) a.heavy_list[b + __popcll(bm & ((1ull << lane) - 1))] = my_rs;
-          }
-          if (bh) {  // back of the list: k_coalesce_heavy
-              uint32_t b = 0;
-              if (lane == 0) b = atomicAdd(co_heavy_count(a), (uint32_t)__popcll(bh));
-              b = __builtin_amdgcn_readfirstlane(b);
-              if (heavy) a.heavy_list[a.n_strands - 1 - (b + __popcll(bh & ((1ull << lane) - 1)))] = my_rs;
-          }
-      }
-      unsigned long long small = __ballot(my_nh >= 1 && my_nh <= 16);
-      while (small) {
-        // the next four strands of this class, one per group (lane number inside the 64; 64 = none left)
-        uint32_t src = 64;
-        {
-            unsigned long long m = small;
-#pragma unroll
-            for (uint32_t g4 = 0; g4 < 4; g4++) {
-                const uint32_t s_g = m ? (uint32_t)__ffsll((long long)m) - 1 : 64u;
-                if (m) m &= m - 1;
-                if ((lane >> 4) == g4) src = s_g;
-            }
-            small = m;
-        }
-        const uint32_t gl = lane & 15, gbase = lane & 48;
-        const bool gvalid = src < 64;
-        const uint32_t grs = base64 + src;
-        const uint32_t go = (uint32_t)__shfl((int)my_o, (int)(src & 63)), gnh_raw = (uint32_t)__shfl((int)my_nh, (int)(src & 63));
-        const uint32_t gnh = gvalid ? gnh_raw : 0;
-        const bool big = false;
-        uint32_t maxnh = gnh;
-        maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 16));
-        maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 32));
-        maxnh = __builtin_amdgcn_readfirstlane(maxnh);
-        StrandGeom gg{0, 0, 1};
-        bool hopeless = false;  // group-uniform: k_thin's flag (see kHopeless)
-        if (gvalid && gnh) {
-            const uint32_t ns_raw = a.strand_nseeds[grs];
-            hopeless = (ns_raw & kHopeless) != 0;
-            gg = strand_geom(a.read_off, a.r0 + (grs >> 1), ns_raw);
-        }
-        uint64_t key = gl < gnh ? ((uint64_t)a.hit_ref[go + gl] << 32) | a.hit_q[go + gl] : ~0ull;
-        for (uint32_t k = 2; k <= 16; k <<= 1)  // bitonic sort inside the 16-lane group
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                uint64_t other = __shfl_xor(key, j);
-                bool up = (gl & k) == 0, lower = (gl & j) == 0;
-                key = (lower == up) ? min(key, other) : max(key, other);
-            }
-        uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-        uint32_t b = 0, ws = 0, we = 0, btax = 0;
-        bool ok = false;
-        if (gl < gnh) {
-            b = min(find_bin(ix, site), ix.n_bins - 1);
-            DevBin bin = ix.bins[b];
-            btax = bin.tax_id;  // travels with the walk: no dependent reload of the candidate's bin
-            ok = candidate_window(site, q, bin, gg.L, gg.ED, &ws, &we);
-        }
-        Walk w{false, 0, 0, 0, 0};
-        uint32_t wtax = 0;
-        uint32_t gnc = 0, ms = 0, me = 0, mb = 0, mn = 0, mtax = 0;
-        for (uint32_t i = 0; i < maxnh; i++) {
-            const int src = (int)(gbase + i);
-            uint32_t wsi = (uint32_t)__shfl((int)ws, src), wei = (uint32_t)__shfl((int)we, src);
-            uint32_t bi = (uint32_t)__shfl((int)b, src), ti = (uint32_t)__shfl((int)btax, src);
-            bool oki = __shfl((int)ok, src) != 0;
-            if (i < gnh) {
-                bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
-                if (merge) {
-                    w.s = min(w.s, wsi);
-                    w.e = max(w.e, wei);
-                    w.n++;
-                } else {
-                    if (w.have && w.n >= gg.min_seeds) {
-                        if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
-                        gnc++;
-                    }
-                    w.have = oki;
-                    w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
-                    wtax = ti;
-                }
-            }
-        }
-        if (w.have && w.n >= gg.min_seeds) {
-            if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
-            gnc++;
-        }
-        uint32_t maxnc = gnc;
-        maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 16));
-        maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 32));
-        maxnc = __builtin_amdgcn_readfirstlane(maxnc);
-        const uint32_t tax = gl < gnc ? mtax : 0;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < maxnc; j++) {
-            uint32_t nj = (uint32_t)__shfl((int)mn, (int)(gbase + j));
-            if (j < gnc) rank += (nj > mn) || (nj == mn && j < gl);
-        }
-        uint32_t nxt = 0xffffffffu;
-        bool first = gl < gnc;
-        for (uint32_t j = 0; j < maxnc; j++) {
-            uint32_t tj = (uint32_t)__shfl((int)tax, (int)(gbase + j)), rj = (uint32_t)__shfl((int)rank, (int)(gbase + j));
-            if (j < gnc) {
-                if (tj == tax && rj > rank && rj < nxt) nxt = rj;
-                if (tj == tax && rj < rank) first = false;
-            }
-        }
-        if (gl < gnc && !hopeless) {
-            a.cand[go + rank] = make_uint4(ms, me, mb, grs);
-            a.cand_next[go + rank] = nxt;
-            a.cand_status[go + rank] = 0;
-        }
-        // a hopeless strand: the reference prefilters each of its candidates (up to max_candidates) and none can
-        // pass; that work is accounted here and the strand leaves the pipeline (no candidates to resolve)
-        const int hw = row_sum16((hopeless && gl < gnc && rank < a.maxc) ? (int)(me - ms) : 0);
-        if (gvalid && gl == 0 && !big) a.strand_ncand[grs] = hopeless ? 0 : gnc;
-        if (gl == 0) {
-            cand_sum += gnc;
-            if (hopeless) {
-                ver_sum += min(gnc, a.maxc);
-                win_sum += (uint32_t)hw;
-            }
-        }
-        {
-            bool emit = first && rank < a.maxc && !hopeless;
-            unsigned long long em = __ballot(emit);
-            uint32_t m = __popcll(em);
-            if (pend + m > kWave) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
-                base = __builtin_amdgcn_readfirstlane(base);
-                wave_mem_sync();
-                if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
-                wave_mem_sync();
-                pend = 0;
-            }
-            if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = go + rank;
-            pend += m;
-        }
-      }
-    }
-    if (pend) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
-        base = __builtin_amdgcn_readfirstlane(base);
-        wave_mem_sync();
-        if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
-    }
-    for (int d = 32; d > 0; d >>= 1) {
-        cand_sum += __shfl_down(cand_sum, d);
-        ver_sum += __shfl_down(ver_sum, d);
-        win_sum += __shfl_down(win_sum, d);
-    }
-    if (lane == 0 && cand_sum) atomicAdd(co_n_cand(a), cand_sum);
-    if (lane == 0 && ver_sum) {  // the counters sit side by side: n_candidates, n_verified, window_bytes
-        atomicAdd(co_n_cand(a) + 1, ver_sum);
-        atomicAdd(co_n_cand(a) + 2, win_sum);
-    }
-}
-
-// Strands of the list with 17..64 seed hits: one wavefront each, everything in registers.
-// one strand of 17..64 seed hits on one wavefront; returns its candidate count.  Not inlined on purpose: the
-// caller's loop state and the argument block would otherwise all be live across this body (SGPR spills).
-__device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndexView& ix, const CoalesceArgs& a, uint32_t rs, uint32_t o,
-                                                                    uint32_t nh, uint32_t* pend_buf, uint32_t& pend) {
-    const uint32_t lane = lane_id();
-    const uint32_t ns_raw = a.strand_nseeds[rs];
-    const bool hopeless = (ns_raw & kHopeless) != 0;  // see k_coalesce
-    const StrandGeom g = strand_geom(a.read_off, a.r0 + (rs >> 1), ns_raw);
-    uint32_t nc = 0;
-    // ---- registers only ----
-    uint64_t key = lane < nh ? ((uint64_t)a.hit_ref[o + lane] << 32) | a.hit_q[o + lane] : ~0ull;
-    key = wave_bitonic_sort(key);  // seed_hits.sort(): (reference_offset, query_offset), index.rs:443
-    uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-    uint32_t b = 0, ws = 0, we = 0;
-    bool ok = false;
-    if (lane < nh) {
-        b = min(find_bin(ix, site), ix.n_bins - 1);
-        DevBin bin = ix.bins[b];
-        ok = candidate_window(site, q, bin, g.L, g.ED, &ws, &we);
-    }
-    Walk w{false, 0, 0, 0, 0};
-    uint32_t ms = 0, me = 0, mb = 0, mn = 0;
-    for (uint32_t i = 0; i < nh; i++) {
-        uint32_t wsi = (uint32_t)__shfl((int)ws, (int)i), wei = (uint32_t)__shfl((int)we, (int)i);
-        uint32_t bi = (uint32_t)__shfl((int)b, (int)i);
-        bool oki = (uint32_t)__shfl((int)ok, (int)i) != 0;
-        bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
-        if (merge) {  // add_seed_hit, index.rs:216-229
-            w.s = min(w.s, wsi);
-            w.e = max(w.e, wei);
-            w.n++;
-        } else {
-            if (w.have && w.n >= g.min_seeds) {  // index.rs:467-469
-                if (lane == nc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
-                nc++;
-            }
-            w.have = oki;  // ReferenceCandidate::new, index.rs:472,475
-            w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
-        }
-    }
-    if (w.have && w.n >= g.min_seeds) {  // index.rs:481-485
-        if (lane == nc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; }
-        nc++;
-    }
-    // stable sort by num_seeds descending (index.rs:369) as a rank computation
-    uint32_t rank = 0;
-    for (uint32_t j = 0; j < nc; j++) {
-        uint32_t nj = (uint32_t)__shfl((int)mn, (int)j);
-        rank += (nj > mn) || (nj == mn && j < lane);
-    }
-    // same-TaxID chain in rank order: a candidate is verified only after every earlier candidate
-    // of its TaxID has failed (index.rs:393), so only the first of each TaxID starts as work
-    uint32_t tax = lane < nc ? ix.bins[mb].tax_id : 0;
-    uint32_t nxt = 0xffffffffu;
-    bool first = lane < nc;
-    for (uint32_t j = 0; j < nc; j++) {
-        uint32_t tj = (uint32_t)__shfl((int)tax, (int)j), rj = (uint32_t)__shfl((int)rank, (int)j);
-        if (tj == tax && rj > rank && rj < nxt) nxt = rj;
-        if (tj == tax && rj < rank) first = false;
-    }
-    if (hopeless) {
-        unsigned long long wsum = (lane < nc && rank < a.maxc) ? me - ms : 0;
-        for (int d = 32; d > 0; d >>= 1) wsum += __shfl_down(wsum, d);
-        if (lane == 0) {
-            a.strand_ncand[rs] = 0;
-            atomicAdd(co_n_cand(a) + 1, (unsigned long long)min(nc, a.maxc));
-            atomicAdd(co_n_cand(a) + 2, wsum);
-        }
-        return nc;
-    }
-    if (lane < nc) {
-        a.cand[o + rank] = make_uint4(ms, me, mb, rs);
-        a.cand_next[o + rank] = nxt;
-        a.cand_status[o + rank] = 0;
-    }
-    if (lane == 0) a.strand_ncand[rs] = nc;
-    {
-        bool emit = first && rank < a.maxc;
-        unsigned long long em = __ballot(emit);
-        uint32_t m = __popcll(em);
-        if (pend + m > kWave) {  // flush the buffered items with one atomic
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
-            base = __builtin_amdgcn_readfirstlane(base);
-            if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
-            pend = 0;
-        }
-        if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = o + rank;
-        pend += m;
-    }
-    return nc;
-}
-
-__global__ __launch_bounds__(256) void k_coalesce_mid(DevIndexView ix, CoalesceArgs a) {
-    __shared__ uint32_t pend_all[256 / kWave][kWave];
-    uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
-    const uint32_t lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
-    const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
-    const uint32_t n_list = *co_mid_count(a);
-    uint32_t pend = 0;
-    unsigned long long cand_sum = 0;
-    for (uint32_t h = wave; h < n_list; h += n_waves) {
-        const uint32_t rs = a.heavy_list[h];
-        const uint32_t o = a.strand_off[rs];
-        const uint32_t nh = __builtin_amdgcn_readfirstlane(a.strand_off[rs + 1] - o);
-        const uint32_t nc = coalesce_mid_strand(ix, a, rs, o, nh, pend_buf, pend);  // writes strand_ncand
-        if (lane == 0) cand_sum += nc;
-    }
-    if (pend) {
-        uint32_t base = 0;
-        if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
-        base = __builtin_amdgcn_readfirstlane(base);
-        wave_mem_sync();
-        if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
-    }
-    for (int d = 32; d > 0; d >>= 1) cand_sum += __shfl_down(cand_sum, d);
-    if (lane == 0 && cand_sum) atomicAdd(co_n_cand(a), cand_sum);
-}
 
 // ---------------------------------------------------------------------------------------------
 // K4: verification.  A wavefront is four 16-lane groups (one DPP row each); every group walks the
@@ -2453,126 +1210,6 @@ __global__ __launch_bounds__(256) void k_gather(uint32_t n_strands, uint64_t r0,
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
-static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
-// --max-candidates as a bound on candidate ranks (index.rs:385-389): None = no bound
-static inline uint32_t rank_bound(int64_t max_candidates) {
-    return max_candidates < 0 ? 0xffffffffu : (max_candidates > 0xfffffffeLL ? 0xfffffffeu : (uint32_t)max_candidates);
-}
-
-void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end) {
-    begin &= ~15ull;  // whole 16-byte groups (a neighbouring range may write the same codes into a shared group)
-    if (end <= begin) return;
-    const uint64_t n = end - begin;
-    hipLaunchKernelGGL(k_normalise, dim3(cdiv((n + 15) / 16, 256)), dim3(256), 0, s, src + begin, dst + begin, n);
-}
-
-void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
-                   uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt) {
-    uint64_t total = (uint64_t)n_reads * 2 * max_ns;
-    if (!total) return;
-    const bool fast = ix.kmer_tab && total < 0xffffffffull && K >= 16 && K <= 24 && ix.kmer_k >= 12 && ix.kmer_k <= 16 &&
-                      K >= ix.kmer_k && K - ix.kmer_k <= 8 && !getenv("MTSV_SEARCH_GENERIC");
-    if (!fast) {
-        hipLaunchKernelGGL(k_search, dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, n_reads, max_ns, K, G,
-                           seed_lo, seed_cnt);
-        return;
-    }
-#define FAST_CASE(KKV)                                                                                                  \
-    hipLaunchKernelGGL((k_search_fast<KKV>), dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, (uint32_t)total, \
-                       max_ns, K, G, seed_lo, seed_cnt)
-    switch (ix.kmer_k) {
-    case 12: FAST_CASE(12); break;
-    case 13: FAST_CASE(13); break;
-    case 14: FAST_CASE(14); break;
-    case 15: FAST_CASE(15); break;
-    default: FAST_CASE(16); break;
-    }
-#undef FAST_CASE
-}
-
-void launch_thin(hipStream_t s, const uint8_t* bases, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, double edit_rate,
-                 double min_seed, uint32_t max_ns, uint32_t K, uint32_t G, uint64_t max_hits, uint64_t tune, uint32_t* seed_cnt, uint32_t* seed_pre,
-                 uint32_t* strand_hits, uint32_t* strand_nseeds) {
-    hipLaunchKernelGGL(k_thin, dim3(cdiv((uint64_t)n_reads * 2, 256)), dim3(256), 0, s, bases, read_off, r0, n_reads, edit_rate,
-                       min_seed, max_ns, K, G, max_hits, tune, seed_cnt, seed_pre, strand_hits, strand_nseeds);
-}
-
-void launch_scan(hipStream_t s, const uint32_t* in, uint32_t n, uint64_t* tile_sums, uint64_t* total, uint32_t* out) {
-    uint32_t tiles = cdiv(n ? n : 1, kScanTile);
-    hipLaunchKernelGGL(k_scan_tile_sums, dim3(tiles), dim3(kScanThreads), 0, s, in, n, tile_sums);
-    hipLaunchKernelGGL(k_scan_sums, dim3(1), dim3(1024), 0, s, tile_sums, tiles, total);
-    hipLaunchKernelGGL(k_scan_apply, dim3(tiles), dim3(kScanThreads), 0, s, in, n, tile_sums, total, out);
-}
-uint32_t scan_tiles(uint32_t n) { return cdiv(n ? n : 1, kScanTile); }
-
-void launch_expand(hipStream_t s, const DevIndexView& ix, uint32_t n_strands, uint32_t max_ns, uint32_t G,
-                   const uint32_t* seed_lo, const uint32_t* seed_cnt, const uint32_t* seed_pre, const uint32_t* strand_off,
-                   uint32_t* hit_row, uint32_t* hit_ref, uint32_t* hit_q) {
-    uint64_t n_slots = (uint64_t)n_strands * max_ns;
-    if (!n_slots) return;
-    hipLaunchKernelGGL(k_expand, dim3(cdiv(n_slots, 256)), dim3(256), 0, s, ix, n_slots, max_ns, G, seed_lo, seed_cnt, seed_pre,
-                       strand_off, hit_row, hit_ref, hit_q);
-}
-
-void launch_locate(hipStream_t s, const DevIndexView& ix, uint32_t total_hits_host, const uint32_t* total_hits_dev,
-                   const uint32_t* hit_row, uint32_t* hit_ref, unsigned long long* lf_steps) {
-    if (!total_hits_host) return;
-    uint32_t chunks = cdiv(total_hits_host, kLocateChunk);
-    uint32_t blocks = std::min<uint32_t>(cdiv(chunks, 4), 256 * 8);
-    hipLaunchKernelGGL(k_locate, dim3(blocks), dim3(256), 0, s, ix, total_hits_dev, hit_row, hit_ref, lf_steps);
-}
-
-void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read_off, uint32_t r0, uint32_t n_strands,
-                     int64_t max_candidates, const uint32_t* strand_off,
-                     const uint32_t* strand_nseeds, const uint32_t* hit_ref, const uint32_t* hit_q, uint64_t* hit_key,
-                     uint64_t* cand_tmp, uint4* cand, uint32_t* cand_next, uint32_t* cand_status,
-                     uint32_t* strand_ncand, uint32_t* worklist, uint32_t* heavy_list, uint64_t* counters) {
-    uint32_t* wl_count = reinterpret_cast<uint32_t*>(counters + 1);
-    uint32_t* heavy_count = wl_count + 1;
-    unsigned long long* n_cand_total = reinterpret_cast<unsigned long long*>(counters + 3);
-    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n_strands, 16), 256 * 8));  // 4 strands per wavefront pass
-    CoalesceArgs c;
-    c.read_off = read_off;
-    c.r0 = r0;
-    c.n_strands = n_strands;
-    c.maxc = rank_bound(max_candidates);
-    c.strand_off = strand_off;
-    c.strand_nseeds = strand_nseeds;
-    c.hit_ref = hit_ref;
-    c.hit_q = hit_q;
-    c.cand = cand;
-    c.cand_next = cand_next;
-    c.cand_status = cand_status;
-    c.strand_ncand = strand_ncand;
-    c.worklist = worklist;
-    c.heavy_list = heavy_list;
-    c.counters = counters;
-    hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, c);
-    // the list of longer strands is short (device-side count): a modest grid of wavefronts walks it
-    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 1024)), dim3(256), 0, s, ix, c);
-    HeavyArgs a;
-    a.read_off = read_off;
-    a.r0 = r0;
-    a.maxc = rank_bound(max_candidates);
-    a.strand_off = strand_off;
-    a.strand_nseeds = strand_nseeds;
-    a.hit_ref = hit_ref;
-    a.hit_q = hit_q;
-    a.hit_key = hit_key;
-    a.cand_tmp = cand_tmp;
-    a.cand = cand;
-    a.cand_next = cand_next;
-    a.cand_status = cand_status;
-    a.strand_ncand = strand_ncand;
-    a.worklist = worklist;
-    a.wl_count = wl_count;
-    a.n_cand_total = n_cand_total;
-    // persistent workgroups over the (device-side) list of heavy strands; usually a few thousand at most
-    const dim3 hgrid(std::min<uint32_t>(std::max<uint32_t>(n_strands / 64, 1), 2048));
-    hipLaunchKernelGGL(k_coalesce_heavy<kHeavyKeysSmall>, hgrid, dim3(256), 0, s, ix, a, heavy_list, n_strands, heavy_count);
-    hipLaunchKernelGGL(k_coalesce_heavy<kHeavyKeys>, dim3(std::min<uint32_t>(hgrid.x, 512)), dim3(256), 0, s, ix, a, heavy_list, n_strands, heavy_count);
-}
-
 void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len) {
     EvalArgs a = a_;
     a.maxc = rank_bound(a.max_candidates);
@@ -2591,30 +1228,6 @@ void launch_evaluate(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, 
     else if (max_len <= kMaxRegisterReadLen) EVAL_CASE(16, true, 16);
     else throw std::runtime_error("internal: launch_evaluate called for a read beyond the register-resident kernels");
 #undef EVAL_CASE
-}
-
-// longest candidate window of a pass (the tiled kernel's strips are sized from it)
-namespace {
-__global__ __launch_bounds__(256) void k_max_window(uint32_t n_strands, const uint32_t* __restrict__ strand_off,
-                                                    const uint32_t* __restrict__ strand_ncand, const uint4* __restrict__ cand,
-                                                    unsigned long long* __restrict__ out) {
-    const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
-    uint32_t m = 0;
-    if (rs < n_strands) {
-        const uint32_t o = strand_off[rs], nc = strand_ncand[rs];
-        for (uint32_t i = 0; i < nc; i++) {
-            const uint4 c = cand[o + i];
-            m = max(m, c.y - c.x);
-        }
-    }
-    for (int d = 32; d > 0; d >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, d));
-    if (lane_id() == 0 && m) atomicMax(out, (unsigned long long)m);
-}
-}  // namespace
-
-void launch_max_window(hipStream_t s, uint32_t n_strands, const uint32_t* strand_off, const uint32_t* strand_ncand,
-                       const uint4* cand, unsigned long long* out) {
-    hipLaunchKernelGGL(k_max_window, dim3(cdiv(n_strands, 256)), dim3(256), 0, s, n_strands, strand_off, strand_ncand, cand, out);
 }
 
 uint32_t tiled_groups(uint64_t max_items, uint32_t strip_len) {

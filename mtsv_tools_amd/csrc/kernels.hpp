@@ -1,4 +1,24 @@
-// kernels.hpp -- launch interface of the hot-path kernels (kernels.hip).
+// kernels.hpp -- launch interface of the hot-path kernels.
+//
+// The mtsv-binner hot path as gfx950 kernels (k_seed.hip, k_coalesce.hip, k_verify.hip).
+//
+// One batch of reads flows through staged kernels with worklists in HBM:
+//
+//   k_search    lane per (read, strand, seed): FMIndex::backward_search           index.rs:305
+//   k_thin      lane per strand: adaptive seed thinning / max_hits filter         index.rs:293-344,354
+//   scan        exclusive scan of per-strand seed-hit counts
+//   k_expand    lane per kept seed: its SA rows / text positions (Interval::occ)  index.rs:347-352
+//   k_locate    lane per seed hit with wavefront refill: SampledSuffixArray::get  index.rs:347
+//   k_coalesce  wavefront per strand: sort, coalesce_seed_sites, min_seeds, rank  index.rs:358-369,435-487
+//   k_sw_pairs  16-lane group per two candidates: the SW prefilter                index.rs:401-406, ssw.c:123-328
+//   k_edit_myers  lane per candidate that passed it: bit-vector edit distance     index.rs:407-410, align.rs:28-85
+//               (rounds follow the same-TaxId chains of the ordered loop)
+//   k_evaluate  longer reads (tiled beyond 256 bases): both in one sweep + sw_sse2_word  ssw.c:354-530
+//   k_resolve   lane per strand: cut-offs and rank order of the selection loop    index.rs:384-428
+//   scan + k_gather  compact per-strand hits into (read, strand, rank) order      binner.rs:128
+//
+// All arithmetic is integer; positions are u32 (n < 2^32).  No MFMA: the path is rank queries and
+// small dynamic programs.
 #pragma once
 #include <algorithm>
 

@@ -5,7 +5,7 @@ kernel spills registers.
 Usage: hipcc ... -Rpass-analysis=kernel-resource-usage -c x.hip 2> remarks.txt
        tools/kernel_resources.py remarks.txt [--guard] [--max-sgpr N]
 
-The guard exists because register spills in the group-divergent kernels of kernels.hip (SGPR spills
+The guard exists because register spills in the group-divergent kernels of k_verify.hip / k_coalesce.hip (SGPR spills
 travel through VGPR lanes with v_writelane/v_readlane; VGPR spills go to scratch under the current
 exec mask) are the first suspect of a wrong-result build seen in round 1.
 """
