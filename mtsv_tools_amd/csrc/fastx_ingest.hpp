@@ -447,10 +447,12 @@ class GzFastx {
             cv_.notify_all();
         };
         while (!gz_.at_end()) {
+            bool stopping;
             {
                 std::lock_guard<std::mutex> lk(mu_);
-                if (stop_) return finish(UINT64_MAX);
+                stopping = stop_;
             }
+            if (stopping) return finish(UINT64_MAX);  // (finish takes the mutex itself)
             if (!gz_.next_round(pieces)) return finish(carry_off);  // nothing at or after carry_off has been handed out
             for (auto& piece : pieces) {
                 std::vector<uint8_t> buf;

@@ -151,6 +151,7 @@ struct Inflater {
     Symbols* out;
     std::vector<Member>* members;
     bool text_only;  // entry-point validation: stop with an error at the first byte that is not text
+    uint64_t stop_symbols = ~0ull;  // validation: leave a block once this many symbols are out
     std::string err;
     Huff lit, dist;
     Inflater(const uint8_t* b, const uint8_t* e, uint64_t bitpos, Symbols* o, std::vector<Member>* m, bool text)
@@ -252,6 +253,10 @@ struct Inflater {
     }
     bool inflate_block_body() {
         for (;;) {
+            // past the end of the input the reader supplies zero bits: a code set in which those decode to a literal
+            // would otherwise never stop (entry-point validation runs on arbitrary bit positions)
+            if (br.p > br.end + 8) return fail("truncated");
+            if (out->s.size() >= stop_symbols) return true;  // validation: enough seen (run() stops at its limit next)
             br.refill();
             const uint16_t e = lit.tab[br.peek(lit.bits)];
             if (!e) return fail("bad literal/length symbol");
@@ -309,6 +314,7 @@ struct Inflater {
     //   AT_EOF     after the last member of the file.
     // *next_bit = position of the next unread block header (or of the end of the file).
     Stop run(uint64_t target, uint64_t limit_bits, uint64_t max_symbols, uint64_t* next_bit) {
+        stop_symbols = max_symbols;
         if (max_symbols == ~0ull && limit_bits != ~0ull) {  // a real chunk: room for ~5x its compressed size up front
             const uint64_t at = br.bitpos();
             if (limit_bits > at) out->s.reserve(out->s.size() + (limit_bits - at) / 8 * 5 + (1 << 16));
@@ -324,6 +330,7 @@ struct Inflater {
                 const uint32_t len = br.get(16), nlen = br.get(16);
                 if ((len ^ nlen) != 0xffffu) return fail("bad stored block"), FAILED;
                 for (uint32_t i = 0; i < len; i++) {
+                    if (br.p > br.end + 8) return fail("truncated"), FAILED;
                     const uint32_t c = br.get(8);
                     if (text_only && !is_text(c)) return fail("binary data"), FAILED;
                     out->s.push_back((uint16_t)c);
@@ -336,6 +343,10 @@ struct Inflater {
                 if (!read_dynamic() || !inflate_block_body()) return FAILED;
             } else {
                 return fail("bad block type"), FAILED;
+            }
+            if (out->s.size() >= max_symbols) {  // validation stopped inside the block
+                *next_bit = br.bitpos();
+                return AT_LIMIT;
             }
             if (bfinal) {
                 br.align_byte();
