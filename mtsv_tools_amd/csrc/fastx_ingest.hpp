@@ -401,8 +401,10 @@ class GzFastx {
 
    private:
     struct Task {
-        std::vector<uint8_t> data;
-        uint64_t offset = 0;  // of data[0] in the decompressed stream
+        std::shared_ptr<std::vector<uint8_t>> keep;  // the buffer ptr points into (a whole inflated piece, or a small copy)
+        const uint8_t* ptr = nullptr;
+        uint64_t len = 0;
+        uint64_t offset = 0;  // of ptr[0] in the decompressed stream
         bool first = false, last = false, ok = true;
         ReadBlock block;
     };
@@ -420,9 +422,11 @@ class GzFastx {
     }
 
     // hand a block to the parsers (bounded number in flight); false when stopping
-    bool submit(std::vector<uint8_t>&& data, uint64_t offset, bool first, bool last) {
+    bool submit(std::shared_ptr<std::vector<uint8_t>> keep, const uint8_t* ptr, uint64_t len, uint64_t offset, bool first, bool last) {
         auto t = std::make_unique<Task>();
-        t->data = std::move(data);
+        t->keep = std::move(keep);
+        t->ptr = ptr;
+        t->len = len;
         t->offset = offset;
         t->first = first;
         t->last = last;
@@ -435,9 +439,12 @@ class GzFastx {
         return true;
     }
 
+    // The inflated pieces are parsed in place: blocks are (pointer, length) views into a piece, cut at record
+    // boundaries; only the record that straddles two pieces is copied (tail of one piece + head of the next).
     void produce() {
-        std::vector<uint8_t> carry;
-        uint64_t carry_off = 0;  // decompressed offset of carry[0]
+        using Buf = std::shared_ptr<std::vector<uint8_t>>;
+        std::vector<uint8_t> carry;  // unparsed tail of the previous piece (less than a block, usually less than a record)
+        uint64_t carry_off = 0;      // decompressed offset of carry[0]
         bool first = true;
         std::vector<std::vector<uint8_t>> pieces;
         auto finish = [&](uint64_t failed_at) {
@@ -455,28 +462,65 @@ class GzFastx {
             if (stopping) return finish(UINT64_MAX);  // (finish takes the mutex itself)
             if (!gz_.next_round(pieces)) return finish(carry_off);  // nothing at or after carry_off has been handed out
             for (auto& piece : pieces) {
-                std::vector<uint8_t> buf;
-                if (carry.empty()) buf = std::move(piece);
-                else {
-                    buf = std::move(carry);
-                    buf.insert(buf.end(), piece.begin(), piece.end());
-                    std::vector<uint8_t>().swap(piece);
-                }
-                carry.clear();
-                uint64_t pos = 0;
-                while (buf.size() - pos > block_) {
-                    const uint64_t b = ParallelFastx::find_boundary_in(buf.data(), buf.size(), fastq_, pos + block_);
-                    if (b == UINT64_MAX || b <= pos) break;
-                    if (!submit(std::vector<uint8_t>(buf.begin() + (ptrdiff_t)pos, buf.begin() + (ptrdiff_t)b), carry_off + pos, first, false)) return finish(UINT64_MAX);
+                if (piece.empty()) continue;
+                Buf pb = std::make_shared<std::vector<uint8_t>>(std::move(piece));
+                const uint8_t* d = pb->data();
+                const uint64_t n = pb->size();
+                uint64_t pos = 0;  // bytes of this piece already handed out (or moved into the straddling block)
+                if (!carry.empty()) {
+                    // first record start inside the piece: the carry plus everything before it is one block
+                    uint64_t b0 = ParallelFastx::find_boundary_in(d, n, fastq_, 1);
+                    if (b0 == UINT64_MAX) {  // no boundary in the whole piece: keep collecting
+                        carry.insert(carry.end(), d, d + n);
+                        if (carry.size() > (1ull << 30)) {  // a gigabyte without a record start: not FASTA / FASTQ
+                            Buf cb = std::make_shared<std::vector<uint8_t>>(std::move(carry));
+                            if (!submit(cb, cb->data(), cb->size(), carry_off, first, false)) return finish(UINT64_MAX);
+                            return finish(UINT64_MAX);
+                        }
+                        continue;
+                    }
+                    Buf sb = std::make_shared<std::vector<uint8_t>>(std::move(carry));
+                    sb->insert(sb->end(), d, d + b0);
+                    carry.clear();
+                    if (!submit(sb, sb->data(), sb->size(), carry_off, first, false)) return finish(UINT64_MAX);
                     first = false;
+                    carry_off += sb->size();
+                    pos = b0;
+                }
+                while (n - pos > block_) {
+                    const uint64_t b = ParallelFastx::find_boundary_in(d, n, fastq_, pos + block_);
+                    if (b == UINT64_MAX || b <= pos) break;
+                    if (!submit(pb, d + pos, b - pos, carry_off, first, false)) return finish(UINT64_MAX);
+                    first = false;
+                    carry_off += b - pos;
                     pos = b;
                 }
-                carry.assign(buf.begin() + (ptrdiff_t)pos, buf.end());
-                carry_off += pos;
+                // what is left may end inside a record: everything up to the last record start that can be verified
+                // goes out as a view, the rest waits for the next piece
+                uint64_t lastb = pos;
+                if (n - pos > 0) {
+                    // search backwards from the end for a record start with some lookahead left behind it
+                    const uint64_t tail = std::min<uint64_t>(n - pos, 1u << 16);
+                    uint64_t t = n - tail;
+                    for (;;) {
+                        const uint64_t b = ParallelFastx::find_boundary_in(d, n, fastq_, std::max<uint64_t>(t, pos + 1));
+                        if (b == UINT64_MAX || b <= lastb) break;
+                        lastb = b;
+                        t = b + 1;
+                    }
+                }
+                if (lastb > pos) {
+                    if (!submit(pb, d + pos, lastb - pos, carry_off, first, false)) return finish(UINT64_MAX);
+                    first = false;
+                    carry_off += lastb - pos;
+                    pos = lastb;
+                }
+                carry.assign(d + pos, d + n);
             }
         }
         if (!carry.empty() || first) {
-            if (!submit(std::move(carry), carry_off, first, true)) return finish(UINT64_MAX);
+            Buf cb = std::make_shared<std::vector<uint8_t>>(std::move(carry));
+            if (!submit(cb, cb->data(), cb->size(), carry_off, first, true)) return finish(UINT64_MAX);
         }
         finish(UINT64_MAX);
     }
@@ -497,8 +541,8 @@ class GzFastx {
                 t = std::move(queue_.front().second);
                 queue_.pop_front();
             }
-            t->ok = ParallelFastx::parse_block(t->data.data(), t->data.size(), fastq_, t->first, t->last, t->block);
-            std::vector<uint8_t>().swap(t->data);
+            t->ok = ParallelFastx::parse_block(t->ptr, t->len, fastq_, t->first, t->last, t->block);
+            t->keep.reset();
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 done_[idx] = std::move(t);
