@@ -418,8 +418,8 @@ int main(int argc, char** argv) {
         mtsv_ingest::ParallelFastx par;
         mtsv_ingest::GzFastx gzpar;  // gzip input: parallel inflate + the same block parsers (MTSV_SERIAL_GZIP=1: zlib's one stream)
         bool use_gz = false;
-        // inflating is the expensive part of gzip input: more helpers than plain text needs (measured: 8 threads 3.1 M
-        // reads/s, 16 4.9, 32 5.4 against 1.3 on zlib's one stream)
+        // inflating is the expensive part of gzip input: more helpers than plain text needs (measured: 8 threads 3.3 M
+        // reads/s, 16 5.5, 32 5.7 against 1.3 on zlib's one stream)
         unsigned gz_threads = host_threads;
         if (!getenv("MTSV_HOST_THREADS")) gz_threads = std::min(std::max(host_threads, 24u), std::max(1u, std::thread::hardware_concurrency()));
         const uint64_t ingest_block = getenv("MTSV_INGEST_BLOCK") ? strtoull(getenv("MTSV_INGEST_BLOCK"), nullptr, 10) : (16ull << 20);
