@@ -77,6 +77,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     if (hit_cap == 0) hit_cap = std::max<uint64_t>(1ull << 20, 32 * ws_reads);
     if (hit_cap > 0xfffffff0ull) hit_cap = 0xfffffff0ull;
     hits_cap = std::max<uint64_t>(1ull << 20, 16 * ws_reads);
+    if (const char* e = getenv("MTSV_HITS_CAP")) hits_cap = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));  // (tests: initial size)
     HIP_CHECK(hipSetDevice(di->device));
     HIP_CHECK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
     const uint64_t ns = 2 * ws_reads;
@@ -802,11 +803,19 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     auto lane_main = [&](Batch* lane) {
         try {
             HIP_CHECK(hipSetDevice(di->device));
+            uint64_t last_done = ~0ull;  // the last slice this lane finished
             for (;;) {
                 uint64_t k;
                 Slice sl;
                 {
                     std::unique_lock<std::mutex> lk(mu);
+                    // The lane's result array only has to hold hits until they have left for the host: once it is half
+                    // full and everything in it has been committed, start again at its beginning (a 100 M-read host
+                    // batch would otherwise pile a third of its hits up on the device).
+                    if (lane->n_hits_total > lane->hits_cap / 2 && (last_done == ~0ull || last_done < next_commit)) {
+                        HIP_CHECK(hipStreamSynchronize(copy_stream2));
+                        lane->n_hits_total = 0;
+                    }
                     cv.wait(lk, [&] {
                         return abort || (next_take < slices.size() && slices[next_take].ready) || (cut_at >= n && next_take >= slices.size());
                     });
@@ -829,6 +838,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     slices[k].hit_off = before;
                     slices[k].hit_cnt = lane->n_hits_total - before;
                     slices[k].done = true;
+                    last_done = k;
                     max_len = std::max(max_len, sl.max_len);
                     free_bufs.push_back(sl.buf);
                     commit_ready();

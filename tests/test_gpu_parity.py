@@ -556,6 +556,25 @@ def test_lanes_do_not_change_hits_or_counters(medium, monkeypatch):
         b.close()
 
 
+def test_run_host_recycles_the_lanes_result_arrays(medium, monkeypatch):
+    """a host batch far larger than the workspace: every lane's device result array is reused once its hits have
+    left for the host (tiny arrays here: dozens of wrap-arounds per lane), growth still works for a slice that
+    needs more, and the hits equal the single-call result"""
+    ix, bases, off = medium
+    ix.to_device(0)
+    want = ix.bin_batch(bases, off, device=0)
+    for lanes, cap in (("1", "20000"), ("3", "40000"), ("3", "2000")):
+        monkeypatch.setenv("MTSV_LANES", lanes)
+        monkeypatch.setenv("MTSV_HITS_CAP", cap)     # initial entries of a lane's result array (grown when a slice needs more)
+        b = M.Batch(ix, 0, 100_000 if lanes == "3" else 6000, 100_000 * 150)
+        monkeypatch.delenv("MTSV_HITS_CAP")
+        b.run_host(bases, off)
+        assert_same_hits(b.download(), want)
+        b.run_host(bases, off)                  # and again on the warm workspace
+        assert_same_hits(b.download(), want)
+        b.close()
+
+
 def test_full_size_properties(medium, tmp_path):
     """size-independent properties at a batch the oracle cannot finish in seconds:
     idempotence, shard invariance (two halves == whole: the multi-GPU read sharding), strand
