@@ -189,7 +189,7 @@ def main():
                           "n_lanes": st.get("n_lanes", 1), "stage_ms": st["stage_ms"], "sw_prefilter_ms": st.get("sw_prefilter_ms"),
                           "config": {"workload": f"{args.workload}: {desc}", "reads": n_reads, "verify_mode": args.verify_mode},
                           "device_counters": {k: st[k] for k in ("n_seed_slots", "n_seed_hits", "n_candidates", "n_verified",
-                                                                  "window_bytes", "n_hits", "sw_cell_pairs")}}))
+                                                                  "window_bytes", "n_hits", "sw_cell_pairs", "n_sw_passed")}}))
         b.close()
         return
 
@@ -427,7 +427,7 @@ def main():
         "overlapped_lanes": overlapped,
         "counters_per_read": ctr_per,
         "device_counters": {k: st1[k] for k in ("n_seed_slots", "n_seed_hits", "lf_steps", "n_candidates",
-                                                 "n_verified", "window_bytes", "n_hits", "n_passes", "sw_cell_pairs")},
+                                                 "n_verified", "window_bytes", "n_hits", "n_passes", "sw_cell_pairs", "n_sw_passed")},
         "parity": parity,
         "other_verify_order": alt,
         "setup_s": {"index_build": t_build, "index_file_reused": index_cached, "index_load": t_load, "index_pack_upload_accel": t_upload},

@@ -192,6 +192,7 @@ void Batch::reset_lane() {
     memset(&stats, 0, sizeof stats);
     memset(stage_acc, 0, sizeof stage_acc);
     sw_ms_acc = 0;
+    sw_passed_acc = 0;
     n_hits_total = 0;
     HIP_CHECK(hipMemsetAsync(d_counters, 0, kCounters * sizeof(uint64_t), stream));
     HIP_CHECK(hipEventRecord(ev[8], stream));
@@ -204,6 +205,7 @@ void Batch::finish_lane() {
     HIP_CHECK(hipEventElapsedTime(&stage_acc[7], ev[8], ev[9]));
     stats.sw_cell_pairs = h_counters[14];
     stats.sw_prefilter_ms = sw_ms_acc;
+    stats.n_sw_passed = sw_passed_acc;
     stats.lf_steps = h_counters[2];
     stats.n_candidates = h_counters[3];
     stats.n_verified = h_counters[4];
@@ -249,6 +251,7 @@ void Batch::end_run() {
         stats.window_bytes += l->stats.window_bytes;
         stats.sw_cell_pairs += l->stats.sw_cell_pairs;
         stats.sw_prefilter_ms += l->stats.sw_prefilter_ms;
+        stats.n_sw_passed += l->stats.n_sw_passed;
     }
     if (overlapped) stage_acc[7] = (float)wall_ms;
     for (int s = 0; s < MTSV_N_STAGES; s++) stats.stage_ms[s] = stage_acc[s];
@@ -519,7 +522,9 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     my.next_count = (uint32_t*)next_slot;
                     launch_edit_myers(stream, v, my, items, pass_max_len, true);
                     HIP_CHECK(hipMemcpyAsync(h_counters + 11, next_slot, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipMemcpyAsync(h_counters + 9, d_counters + 9, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipStreamSynchronize(stream));
+                    sw_passed_acc += h_counters[9] & 0xffffffffull;
                     if (round == 0) {
                         float ms = 0;
                         HIP_CHECK(hipEventElapsedTime(&ms, ev[10], ev[11]));

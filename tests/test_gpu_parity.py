@@ -426,6 +426,7 @@ def test_counters_equal_oracle_counters(small_db):
     assert st["n_verified"] == ctr["n_sw"]
     assert st["window_bytes"] == ctr["W"]
     assert st["n_hits"] == ctr["R"]
+    assert 0 < st["n_sw_passed"] <= ctr["n_edit"]   # equal but for reads with more N than the tolerance (below)
 
 
 @pytest.fixture(scope="module")
@@ -512,6 +513,22 @@ def test_prefilter_shortcuts_for_every_row_count(tricky, max_len, monkeypatch):
         if mode == 0:
             assert (st["n_verified"], st["window_bytes"]) == (ctr["n_sw"], ctr["W"])
             swept["bounds"] = st["sw_cell_pairs"]
+    b.close()
+    # The SW predicate itself (index.rs:406), candidate by candidate in aggregate: the number of candidates the
+    # prefilter passes on equals the number of edit distances the reference computes.  Reads with more N than
+    # the edit tolerance are left out: no candidate of theirs can be accepted, so the coalescing kernels account
+    # their prefilter work without deciding it.
+    import math
+    few_n = [r for r in reads if sum(c not in b"ACGT" for c in r) <= math.ceil(len(r) * op.edit_rate)]
+    assert len(few_n) > 400
+    fb, fo = helpers.reads_to_batch(few_n)
+    fwant, fctr = orc.bin_batch(fb, fo, op, threads=8)
+    b = M.Batch(ix, 0, len(few_n), len(fb))
+    b.upload(fb, fo)
+    b.run(mp)
+    assert_same_hits(b.download(), fwant)
+    st = b.stats()
+    assert (st["n_verified"], st["n_sw_passed"]) == (fctr["n_sw"], fctr["n_edit"]) and fctr["n_edit"] > len(fwant)
     b.close()
     # the instantiation without the lower bounds on the seed diagonal (every candidate that is not hopeless is
     # swept) decides every candidate the same way: same hits, same counters, more cells
