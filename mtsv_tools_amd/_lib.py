@@ -8,7 +8,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 
 
 def lib_path():
-    return os.path.join(_HERE, "libmtsv_amd.so")
+    # MTSV_AMD_LIB: a variant build of the same library (tools/build_variant.sh, kernel experiments)
+    return os.environ.get("MTSV_AMD_LIB") or os.path.join(_HERE, "libmtsv_amd.so")
 
 
 class MtsvError(RuntimeError):

@@ -511,8 +511,27 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     sw.wl_count_slot = round == 0 ? 1u : 11u + ((round - 1) & 1u);
                     sw.pass_list = pass_list;
                     sw.pass_count = (uint32_t*)(d_counters + 9);
+#ifdef MTSV_SW_HIST
+                    if (!d_strip) { uint64_t dummy = 0; dev_alloc(&d_strip, 4096, &dummy); strip_cap = 4096; }
+                    HIP_CHECK(hipMemsetAsync(d_strip, 0, 768 * 4, stream));
+                    sw.strip = d_strip;
+#endif
                     if (round == 0) HIP_CHECK(hipEventRecord(ev[10], stream));
                     launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag);
+#ifdef MTSV_SW_HIST
+                    {
+                        static uint32_t hh[768];
+                        HIP_CHECK(hipMemcpyAsync(hh, d_strip, sizeof hh, hipMemcpyDeviceToHost, stream));
+                        HIP_CHECK(hipStreamSynchronize(stream));
+                        fprintf(stderr, "SWHIST round %u steps/4:", round);
+                        for (int i = 0; i < 128; i++) if (hh[i]) fprintf(stderr, " %d:%u", i * 4, hh[i]);
+                        fprintf(stderr, "\nSWHIST halves sweeping 0/1/2: %u %u %u\nSWHIST fail best:", hh[128], hh[129], hh[130]);
+                        for (int i = 0; i < 256; i++) if (hh[256 + i]) fprintf(stderr, " %d:%u", i, hh[256 + i]);
+                        fprintf(stderr, "\nSWHIST pass best:");
+                        for (int i = 0; i < 256; i++) if (hh[512 + i]) fprintf(stderr, " %d:%u", i, hh[512 + i]);
+                        fprintf(stderr, "\n");
+                    }
+#endif
                     if (round == 0) HIP_CHECK(hipEventRecord(ev[11], stream));
                     EvalArgs my = a;
                     my.worklist = pass_list;

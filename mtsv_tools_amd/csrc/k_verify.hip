@@ -430,6 +430,7 @@ typedef unsigned short upk16 __attribute__((ext_vector_type(2)));
 __device__ inline upk16 as_u2(uint32_t v) { return __builtin_bit_cast(upk16, v); }
 __device__ inline uint32_t as_bits(upk16 v) { return __builtin_bit_cast(uint32_t, v); }
 __device__ inline uint32_t pku_max(uint32_t a, uint32_t b) { return as_bits(__builtin_elementwise_max(as_u2(a), as_u2(b))); }
+__device__ inline uint32_t pku_min(uint32_t a, uint32_t b) { return as_bits(__builtin_elementwise_min(as_u2(a), as_u2(b))); }
 __device__ inline uint32_t pku_add(uint32_t a, uint32_t b) { return as_bits(as_u2(a) + as_u2(b)); }
 __device__ inline uint32_t pku_sub(uint32_t a, uint32_t b) { return as_bits(as_u2(a) - as_u2(b)); }
 __device__ inline uint32_t pku_satsub(uint32_t a, uint32_t b) { return as_bits(__builtin_elementwise_sub_sat(as_u2(a), as_u2(b))); }
@@ -450,7 +451,16 @@ __device__ inline int row_max16(int v) {
 #endif
 constexpr int kSwOcc = MTSV_SW_OCC;  // resident workgroups of k_sw_pairs per CU
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
-constexpr uint32_t kDecide = 32;  // columns between decision points after the two scheduled ones
+#ifndef MTSV_SW_DECIDE
+#define MTSV_SW_DECIDE 8
+#endif
+#ifndef MTSV_SW_SCHED
+#define MTSV_SW_SCHED 1
+#endif
+#ifndef MTSV_SW_SLACK
+#define MTSV_SW_SLACK 4
+#endif
+constexpr uint32_t kDecide = MTSV_SW_DECIDE;  // columns between decision points after the two scheduled ones
 
 constexpr uint32_t kPend = 64;   // passed candidates a group of k_sw_pairs buffers before one atomic
 constexpr uint32_t kClaim = 32;  // work items a group of k_sw_pairs claims with one atomic, at most
@@ -714,23 +724,29 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             // (a base missing from the read, or an extra one), joined by a gap of one.  That alignment
                             // scores at least L - 2 - 2*mismatches, so mismatches <= ED - 1 still proves the
                             // threshold; the split s is tried at every lane boundary with two row scans.
+                            // The window starts at the smallest start any of its seed hits asks for, so the
+                            // read's first rows sit on the middle diagonal when the window's later part is
+                            // shifted right (a base missing from the read) and on the right-hand one when it is
+                            // shifted left (an extra base in the read): both orders of every adjacent pair.
                             if (!decided && EDq >= 1 && EDq + Lq + 1 <= lim) {
-                                int pre = mm[1];  // inclusive prefix sum over the lanes of the row
-                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x111, 0xf, 0xf, true);   // row_shr:1
-                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x112, 0xf, 0xf, true);   // row_shr:2
-                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x114, 0xf, 0xf, true);   // row_shr:4
-                                pre += __builtin_amdgcn_update_dpp(0, pre, 0x118, 0xf, 0xf, true);   // row_shr:8
-                                int best_mm = 0x7fffffff;
+                                int pre[3], suf[3];
 #pragma unroll
-                                for (int d = 0; d < 3; d += 2) {
-                                    int suf = mm[d];  // inclusive suffix sum
-                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x101, 0xf, 0xf, true);  // row_shl:1
-                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x102, 0xf, 0xf, true);  // row_shl:2
-                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x104, 0xf, 0xf, true);  // row_shl:4
-                                    suf += __builtin_amdgcn_update_dpp(0, suf, 0x108, 0xf, 0xf, true);  // row_shl:8
-                                    // split before this lane: lanes < gl on the diagonal (pre - own), this lane and above on d
-                                    best_mm = min(best_mm, pre - mm[1] + suf);
+                                for (int d = 0; d < 3; d++) {
+                                    int v = mm[d];  // inclusive prefix sum over the lanes of the row
+                                    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);   // row_shr:1
+                                    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);   // row_shr:2
+                                    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);   // row_shr:4
+                                    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);   // row_shr:8
+                                    pre[d] = v - mm[d];  // lanes below this one
+                                    int w = mm[d];  // inclusive suffix sum
+                                    w += __builtin_amdgcn_update_dpp(0, w, 0x101, 0xf, 0xf, true);  // row_shl:1
+                                    w += __builtin_amdgcn_update_dpp(0, w, 0x102, 0xf, 0xf, true);  // row_shl:2
+                                    w += __builtin_amdgcn_update_dpp(0, w, 0x104, 0xf, 0xf, true);  // row_shl:4
+                                    w += __builtin_amdgcn_update_dpp(0, w, 0x108, 0xf, 0xf, true);  // row_shl:8
+                                    suf[d] = w;
                                 }
+                                // split before this lane: lanes < gl on one diagonal, this lane and above on its neighbour
+                                int best_mm = min(min(pre[1] + suf[0], pre[1] + suf[2]), min(pre[0] + suf[1], pre[2] + suf[1]));
                                 best_mm = -row_max16(-best_mm);
                                 decided = best_mm <= (int)EDq - 1;
                             }
@@ -765,7 +781,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                     for (int hf = 0; hf < 2; hf++) {
                         if (st[hf] != HF_SWEEP) continue;
                         const uint32_t slack = Wn[hf] > Lh(hf) ? (Wn[hf] - Lh(hf)) / 2 : 0;
-                        tj = max(tj, (Wn[hf] > thrh(hf) ? Wn[hf] - thrh(hf) : 0) + GS + 12);
+                        tj = max(tj, (Wn[hf] > thrh(hf) ? Wn[hf] - thrh(hf) : 0) + GS + MTSV_SW_SLACK);
                         tt = max(tt, slack + thrh(hf) + thrh(hf) / R + 10);
                     }
                     checks = min(max(32u, (tj + 3) & ~3u), 0xfffcu) | (min((tt + 3) & ~3u, 0xfffcu) << 16);
@@ -795,21 +811,29 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
             // maximum reaches the threshold and fails as soon as no alignment through unswept cells can.
             if (__builtin_expect(t >= (checks & 0xffffu), 0)) {
                 int bmax[2], ub[2];
-                // one bound per lane instead of one per row: the lane's largest H with the row count of
-                // its first real row (at most R - 1 looser than the per-row bound of k_evaluate)
-                uint32_t hm = h[0];
+                // A path that leaves the swept cells through row r of this lane (now at column jc) can add
+                // at most min(rows below r, columns right of jc) to H[r]; the rows are bottom-aligned, so
+                // row r of lane gl has (GS - gl) * R - 1 - r read rows below it whatever the read length.
+                // The lane's last row is also left diagonally from its previous column, where H is at most
+                // one larger: + 2.  Padding rows (H = 0) yield the column count, which the bound on
+                // alignments that start in unswept columns covers anyway.  Both halves in packed u16.
+                uint32_t hb;
+                {
+                    const uint32_t cl0 = (uint32_t)max((int)Wn[0] - (int)t + (int)gl, 0), cl1 = (uint32_t)max((int)Wn[1] - (int)t + (int)gl, 0);
+                    const uint32_t cl = min(cl0, 0xffffu) | (min(cl1, 0xffffu) << 16);
+                    uint32_t rl = ((GS - gl) * R - 1) * ONE;
+                    hb = 0;
 #pragma unroll
-                for (int r = 1; r < R; r++) hm = pku_max(hm, h[r]);
+                    for (int r = 0; r < R; r++) {
+                        uint32_t v = pku_add(h[r], pku_min(rl, cl));
+                        if (r == R - 1) v = pku_add(v, TWO);
+                        hb = pku_max(hb, v);
+                        rl = pku_sub(rl, ONE);
+                    }
+                }
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
-                    const int W_ = (int)Wn[hf], L_ = (int)Lh(hf);
-                    const int jl = (int)t - 1 - (int)gl;
-                    const int jc = min(jl, W_ - 1);
-                    const int cols_left = W_ - 1 - jc;
-                    const int pad = (int)(GS * R) - L_;
-                    const int p_first = max((int)(gl * R) - pad, 0), p_last = (int)(gl * R + R - 1) - pad;
-                    const int hv = (int)((hm >> (16 * hf)) & 0xffffu);
-                    ub[hf] = p_last >= 0 ? hv + 2 + min(L_ - 1 - p_first, cols_left) : 0;
+                    ub[hf] = (int)((hb >> (16 * hf)) & 0xffffu);
                     bmax[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;  // best tracks H + 1
                 }
 #pragma unroll
@@ -826,7 +850,15 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                     }
                 }
                 finish = st[0] != HF_SWEEP && st[1] != HF_SWEEP;
+#if MTSV_SW_SCHED == 0
                 checks = (checks >> 16) > t + 8 ? (checks >> 16) : min(t + kDecide, 0xfffcu);  // past 65 k columns: every trip
+#else
+                {
+                    const uint32_t second = checks >> 16;
+                    const uint32_t nx = min(t + kDecide, 0xfffcu);
+                    checks = (second > t + 8 ? min(second, nx) : nx) | (second << 16);
+                }
+#endif
             }
             if (!finish) {
                 // four columns per trip: this lane's columns j0 .. j0+3 of both windows come from the rings as two
@@ -879,6 +911,13 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         if (__builtin_expect(phase == PH_SWEEP && finish, 0)) {
             int bm[2];
             swept += t;
+#ifdef MTSV_SW_HIST
+            if (gl == 0) {
+                uint32_t* hist = reinterpret_cast<uint32_t*>(a.strip);
+                atomicAdd(&hist[min(t / 4, 127u)], 1u);
+                atomicAdd(&hist[128 + (Wn[0] != 0) + (Wn[1] != 0)], 1u);
+            }
+#endif
 
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) bm[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;
@@ -887,6 +926,9 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
                 if (st[hf] == HF_SWEEP) st[hf] = bm[hf] >= (int)thrh(hf) ? HF_PASS : HF_FAIL;
+#ifdef MTSV_SW_HIST
+                if (gl == 0 && Wn[hf] != 0) atomicAdd(&reinterpret_cast<uint32_t*>(a.strip)[256 + (st[hf] == HF_PASS ? 256 : 0) + min(max(bm[hf], 0), 255)], 1u);
+#endif
                 if (st[hf] == HF_PASS) {
                     pass_push(g[hf]);
                 } else if (st[hf] == HF_FAIL) {
