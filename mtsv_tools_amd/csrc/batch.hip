@@ -100,6 +100,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     HIP_CHECK(hipHostMalloc((void**)&h_counters, kCounters * sizeof(uint64_t)));
     if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
     if (const char* e = getenv("MTSV_SW_DIAG")) sw_diag = atoi(e) != 0;
+    if (const char* e = getenv("MTSV_SW_PREPASS")) sw_prepass = atoi(e) != 0;
     verify_mode = g_default_verify_mode;
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
@@ -226,6 +227,7 @@ void Batch::begin_run(const mtsv_params& p) {
         l->verify_mode = verify_mode;
         l->sw_pairs = sw_pairs;
         l->sw_diag = sw_diag;
+        l->sw_prepass = sw_prepass;
         l->reset_lane();
     }
 }
@@ -487,13 +489,16 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                 launch_evaluate_tiled(stream, v, a, total_hits);
             } else if (verify_mode == 1 && pass_max_len <= 253) {
                 launch_edit_myers(stream, v, a, total_hits, pass_max_len);
-            } else if (sw_pairs && pass_max_len <= 253) {
+            } else if (sw_pairs && pass_max_len <= 253 && hit_cap < 0x80000000ull) {  // (bit 31 of a work item is a flag)
                 // Reference order, split by predicate: k_sw_pairs runs the prefilter of index.rs:406 two
                 // candidates per group, k_edit_myers the edit distance of :407-410 on those that passed.
                 // A candidate that passes the first and fails the second sends its TaxId's next
                 // candidate to another round (rare); rounds end when nothing is left.
-                // counters: [8] SW cursor, [9] pass count, [10] Myers cursor, [11]/[12] next-round counts
+                // counters: [8] SW cursor, [9] pass count, [10] Myers cursor, [11]/[12] next-round counts, [16] sweep list
+                // Round 0 starts with k_sw_diag: the lower bounds on the seed diagonal, a lane per work item; what
+                // they decide goes straight to pass_list, the rest to sweep_list for k_sw_pairs.
                 uint32_t* pass_list = (uint32_t*)d_hit_key;                       // coalesce scratch is free now
+                uint32_t* sweep_list = (uint32_t*)d_hit_key + hit_cap;            // (8 bytes per seed hit)
                 uint32_t* next_lists[2] = {(uint32_t*)d_cand_tmp, (uint32_t*)d_cand_tmp + hit_cap};
                 const uint32_t* wl = d_worklist;
                 const uint32_t* wl_count = (const uint32_t*)(d_counters + 1);
@@ -517,6 +522,13 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     sw.strip = d_strip;
 #endif
                     if (round == 0) HIP_CHECK(hipEventRecord(ev[10], stream));
+                    if (round == 0 && sw_diag && sw_prepass) {
+                        HIP_CHECK(hipMemsetAsync(d_counters + 16, 0, sizeof(uint64_t), stream));
+                        launch_sw_diag(stream, v, sw, items, sweep_list, 16);
+                        sw.worklist = sweep_list;
+                        sw.wl_count_slot = 16;
+                        sw.wl_reverse = 0;  // k_sw_diag read the worklist from its end
+                    }
                     launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag);
 #ifdef MTSV_SW_HIST
                     {

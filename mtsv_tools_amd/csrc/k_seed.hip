@@ -336,7 +336,8 @@ __global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases,
         // the two strands of a read sit in neighbouring lanes (rs even / odd): the even lane counts the read's N once
         // for both, and only when one of them has seed hits (only such strands can have candidates)
         const bool need = total != 0;
-        const bool pair_need = need || __shfl_xor((int)need, 1) != 0;
+        const int other_need = __shfl_xor((int)need, 1);  // (unconditionally: both lanes of the pair take part in the exchange)
+        const bool pair_need = need || other_need != 0;
         const uint32_t ED = (uint32_t)ceil((double)L * edit_rate);  // index.rs:281-282
         bool hopeless = 2ull * ED > (uint64_t)L;
         uint32_t nn = 0;

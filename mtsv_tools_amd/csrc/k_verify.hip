@@ -436,6 +436,7 @@ __device__ inline uint32_t pku_sub(uint32_t a, uint32_t b) { return as_bits(as_u
 __device__ inline uint32_t pku_satsub(uint32_t a, uint32_t b) { return as_bits(__builtin_elementwise_sub_sat(as_u2(a), as_u2(b))); }
 
 enum : uint32_t { HF_EMPTY = 0, HF_SWEEP = 1, HF_PASS = 2, HF_FAIL = 3 };
+constexpr uint32_t kSweepFlag = 0x80000000u;  // worklist entry from k_sw_diag: verified/window_bytes counted, bounds tried
 
 // maximum over the 16 lanes of a DPP row, result in every lane: quad swaps, then the two mirrors
 __device__ inline int row_max16(int v) {
@@ -583,7 +584,8 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                                 // wl_reverse: last entries first -- the coalescing kernels append the strands with the most
                                 // seed hits (long same-TaxId chains, long merged windows) last, and the longest items
                                 // should start first, not finish the launch alone
-                                const uint32_t gi = a.worklist[a.wl_reverse ? n_work - 1 - (first + i) : first + i];
+                                const uint32_t ge = a.worklist[a.wl_reverse ? n_work - 1 - (first + i) : first + i];
+                                const uint32_t gi = ge & ~kSweepFlag;  // flagged: k_sw_diag counted it and its bounds do not decide it
                                 const uint4 c = a.cand[gi];
                                 const uint32_t rs = c.w;
                                 const uint32_t r_ = a.r0 + (rs >> 1);
@@ -598,7 +600,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                                 const uint32_t EDi = (uint32_t)ceil((double)Li * a.edit_rate);  // index.rs:281-282
                                 m[5] = Li;
                                 // strand, usize wrap of index.rs:406 (2*ED > L: nothing can pass), ED, threshold L - 2*ED
-                                m[6] = (rs & 1) | (2ull * EDi > (uint64_t)Li ? 2u : 0u) | ((EDi & 0xffu) << 8) | (((Li - 2 * EDi) & 0xffu) << 16);
+                                m[6] = (rs & 1) | (2ull * EDi > (uint64_t)Li ? 2u : 0u) | ((ge >> 31) << 2) | ((EDi & 0xffu) << 8) | (((Li - 2 * EDi) & 0xffu) << 16);
                             }
                             wave_lds_handoff();  // every lane of the group reads the staged items
                         }
@@ -613,7 +615,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                             o[hf] = m[3];
                             b0s[hf] = m[4];
                             geo = (geo & ~(0xffu << (8 * hf))) | ((m[5] & 0xffu) << (8 * hf));
-                            strands[hf] = m[6];  // bit 0 strand, bit 1 wrapped, bits 8-15 ED, 16-23 threshold
+                            strands[hf] = m[6];  // bit 0 strand, bit 1 wrapped, bit 2 counted and bounds tried (k_sw_diag), bits 8-15 ED, 16-23 threshold
                             geo = (geo & ~(0xffu << (16 + 8 * hf))) | (((m[6] >> 16) & 0xffu) << (16 + 8 * hf));
                             wf |= 5u << hf;
                         }
@@ -663,8 +665,10 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         // more N in the read than the edit tolerance: index.rs:410 fails whatever the prefilter says
                         gf = (wrapped || (uint32_t)nn > ED) ? (gf | (F_HOPELESS << hf)) : (gf & ~(F_HOPELESS << hf));
                     }
-                    verified++;
-                    wbytes += cy[hf] - cx[hf];
+                    if (!(strands[hf] & 4u)) {
+                        verified++;
+                        wbytes += cy[hf] - cx[hf];
+                    }
                     if (gf & (F_HOPELESS << hf)) {  // rejected without a sweep; the reference still ran its prefilter on it
                         if (gl == 0) a.cand_status[g[hf]] = 1;
                         const uint32_t nxt = a.cand_next[g[hf]];
@@ -689,7 +693,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         // and the local score is at least that.  mismatches <= ED  =>  score >= L - 2*ED.
                         const uint32_t Lq = Lh(hf), EDq = (Lq - thrh(hf)) / 2;
                         bool decided = false;
-                        if (DIAG && EDq + Lq <= lim) {
+                        if (DIAG && !(strands[hf] & 4u) && EDq + Lq <= lim) {
                             const int pad = (int)(GS * R) - (int)Lq;
                             // the lane's R window symbols on that diagonal (and its two neighbours): aligned dwords +
                             // v_alignbyte; sy[d] faces read position p with window column ED + p + d - 1
@@ -961,6 +965,217 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         atomicAdd((unsigned long long*)a.counters + kCtrVerified, v64);
         atomicAdd((unsigned long long*)a.counters + kCtrWindowBytes, w64);
         if (s64) atomicAdd((unsigned long long*)a.counters + kCtrSwCellPairs, s64 * R);  // cell pairs swept (one packed 7-instruction recurrence each)
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// K4a: the lower bounds of the prefilter on their own (first round of a pass), a 16-lane group per work item.
+// Most candidates that will be accepted are the read's own origin: the read lies on the diagonal the
+// window was cut around (read position 0 faces window column ED, index.rs:128-133) with substitutions
+// only, or with one base missing or extra.  The ungapped alignment on that diagonal scores
+// L - 2*mismatches, one that changes to a neighbouring diagonal once at least L - 2 - 2*mismatches, and
+// the local score ssw.c computes is at least either: mismatches <= ED (ED - 1 with the gap) proves
+// score >= L - 2*ED, the predicate of index.rs:406, without the sweep.  Such a candidate goes to
+// pass_list (k_edit_myers computes its edit distance, :407-410); every other one to sweep_list with
+// bit 31 set, for k_sw_pairs: "counted here, and the bounds do not decide it".
+// Lane gl compares read positions 16*gl .. 16*gl+15 with the three diagonals, four codes per
+// instruction (mismatch = the codes differ, as in the sweep: N faces N as a match,
+// ssw/src/lib.rs:11-16); the change of diagonal is tried after every fourth read position, both
+// orders of every adjacent pair (prefix counts of the lanes below + the best split inside the lane +
+// suffix counts of the lanes above).  Decisions are buffered per wavefront: one atomic per ~120 entries.
+// ---------------------------------------------------------------------------------------------
+__device__ inline uint32_t nz_bytes(uint32_t x) { return (x | (x >> 1) | (x >> 2)) & 0x01010101u; }  // codes < 8
+__device__ inline uint32_t comp_codes4(uint32_t x) {  // 3 - c for the bases, N stays (four codes 0..4)
+    const uint32_t n = (x >> 2) & 0x01010101u;
+    return x ^ ((n ^ 0x01010101u) * 3u);
+}
+__device__ inline int row_prefix_incl16(int v) {  // inclusive prefix sum over the 16 lanes of a DPP row
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    return v;
+}
+__device__ inline int row_suffix_incl16(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x101, 0xf, 0xf, true);  // row_shl:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x102, 0xf, 0xf, true);  // row_shl:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x104, 0xf, 0xf, true);  // row_shl:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x108, 0xf, 0xf, true);  // row_shl:8
+    return v;
+}
+
+constexpr uint32_t kDiagBuf = 128;  // decisions a wavefront of k_sw_diag buffers per list
+
+__global__ __launch_bounds__(256) void k_sw_diag(DevIndexView ix, EvalArgs a, uint32_t* __restrict__ sweep_list, uint32_t sweep_slot) {
+    __shared__ uint32_t buf_all[256 / kWave][2][kDiagBuf];
+    uint32_t* pbuf = buf_all[threadIdx.x / kWave][0];
+    uint32_t* sbuf = buf_all[threadIdx.x / kWave][1];
+    uint32_t np = 0, nsw = 0;  // wave-uniform fill of the two buffers
+    const uint32_t n_work = *reinterpret_cast<const uint32_t*>(a.counters + a.wl_count_slot);
+    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(ix.text);
+    const uint32_t* b32 = reinterpret_cast<const uint32_t*>(a.bases);
+    const uint32_t lastw = (ix.n - 1) >> 2;  // text allocations are padded to a dword multiple
+    const uint32_t lane = lane_id(), gl = lane & 15u;
+    unsigned long long verified = 0, wbytes = 0;
+    auto flush = [&](uint32_t* buf, uint32_t& n, uint32_t* count, uint32_t* list, uint32_t flag) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(count, n);
+        base = (uint32_t)__shfl((int)base, 0);
+        wave_lds_handoff();
+        for (uint32_t j = lane; j < n; j += kWave) list[base + j] = buf[j] | flag;
+        wave_lds_handoff();
+        n = 0;
+    };
+    // The work item's description hangs on three dependent loads (worklist -> candidate -> read offsets); they run
+    // three, two and one items ahead of the comparison, so that an item waits for its bases and text only.
+    // Items in runs of 32 per wavefront (eight trips of four), the runs of all wavefronts side by side in a tile:
+    // neighbours in the worklist are reads next to each other, and they stay neighbours in pass_list (k_edit_myers
+    // works a lane per entry) while the order of the tiles -- from the end of the worklist, where the coalescing
+    // kernels put the strands with the most seed hits -- carries over to sweep_list.
+    auto item_at = [&](uint32_t i) { return a.worklist[a.wl_reverse ? n_work - 1 - i : i]; };
+    const uint32_t n_waves = gridDim.x * (256 / kWave), wave_g = blockIdx.x * (256 / kWave) + threadIdx.x / kWave;
+    auto index_of = [&](uint32_t it) {  // 64-bit: past the last tile the index only has to compare as >= n_work
+        return ((uint64_t)(it >> 3) * n_waves + wave_g) * 32 + (it & 7u) * 4 + (lane >> 4);
+    };
+    const uint32_t trips = (n_work + n_waves * 32 - 1) / (n_waves * 32) * 8;
+    uint32_t gi_2 = 0, gi_1 = 0, gi_0 = 0;      // items two / one ahead, the current one
+    uint4 c_1 = make_uint4(0, 0, 0, 0), c_0 = c_1;
+    uint32_t b0_0 = 0, L_0 = 0;
+    if (index_of(2) < n_work) gi_2 = item_at((uint32_t)index_of(2));
+    if (index_of(1) < n_work) {
+        gi_1 = item_at((uint32_t)index_of(1));
+        c_1 = a.cand[gi_1];
+    }
+    if (index_of(0) < n_work) {
+        gi_0 = item_at((uint32_t)index_of(0));
+        c_0 = a.cand[gi_0];
+        const uint32_t r_ = a.r0 + (c_0.w >> 1);
+        b0_0 = a.read_off[r_];
+        L_0 = a.read_off[r_ + 1] - b0_0;
+    }
+    for (uint32_t it = 0; it < trips; it++) {  // the same trip count for every wavefront
+        const bool have = index_of(it) < n_work;  // group-uniform, like every branch below that holds a row operation
+        // issue the loads of the items ahead
+        uint32_t gi_3 = 0, b0_1 = 0, L_1 = 0;
+        uint4 c_2 = make_uint4(0, 0, 0, 0);
+        if (index_of(it + 3) < n_work) gi_3 = item_at((uint32_t)index_of(it + 3));
+        if (index_of(it + 2) < n_work) c_2 = a.cand[gi_2];
+        if (index_of(it + 1) < n_work) {
+            const uint32_t r1 = a.r0 + (c_1.w >> 1);
+            b0_1 = a.read_off[r1];
+            L_1 = a.read_off[r1 + 1] - b0_1;
+        }
+        bool decided = false;
+        const uint32_t gi = gi_0;
+        if (have) {
+            const uint4 c = c_0;
+            const uint32_t rs = c.w;
+            const uint32_t b0 = b0_0, L = L_0;
+            const uint32_t ED = (uint32_t)ceil((double)L * a.edit_rate);  // index.rs:281-282
+            const uint32_t W = c.y - c.x;
+            if (gl == 0) {
+                verified++;
+                wbytes += W;
+            }
+            if (2ull * ED <= (uint64_t)L && ED + L <= W) {
+                const uint32_t p0 = gl * 16;  // this lane's first read position
+                // read codes of positions p0 .. p0+15 (reverse strand: the complement of bytes b0+L-1-p0 downwards)
+                uint32_t rd[4];
+                {
+                    const bool rev = (rs & 1u) != 0;
+                    // (lanes past the read compare nothing: they load the read's first bytes instead of running off the buffer;
+                    //  word indices below 0 -- the tail of a reverse strand at the buffer's start -- are clamped, those bytes are masked)
+                    const uint32_t pq = p0 < L ? p0 : 0u;
+                    const long long ba = rev ? (long long)b0 + L - 16 - pq : (long long)b0 + pq;
+                    const long long w = ba >> 2;
+                    const uint32_t sh = (uint32_t)(ba & 3);
+                    uint32_t d[5];
+#pragma unroll
+                    for (int k = 0; k < 5; k++) d[k] = b32[max(w + k, 0ll)];  // (the buffer is padded past its end)
+                    uint32_t x[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) rd[k] = rev ? comp_codes4(__builtin_bswap32(x[3 - k])) : x[k];
+                }
+                // window bytes pc - 1 .. pc + 16 around the middle diagonal (byte pc + j faces read position p0 + j)
+                const uint32_t pc = c.x + ED + p0;
+                const uint32_t wi = pc >> 2, sc = pc & 3u;
+                uint32_t wv[6];  // words wi - 1 .. wi + 4
+                // (clamped, not guarded: every byte a valid position compares lies inside the window, hence inside the text;
+                //  the byte before position 0 is only wrong when c.x + ED = 0, where the gap bound -- ED >= 1 -- is not tried)
+                wv[0] = t32[wi >= 1 ? min(wi - 1, lastw) : 0u];
+#pragma unroll
+                for (int k = 0; k < 5; k++) wv[k + 1] = t32[min(wi + k, lastw)];
+                int ca[3][4];  // mismatches per diagonal and group of four positions
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t lo = wv[k + 1], hi = wv[k + 2], bl = wv[k];
+                    const uint32_t s0 = sc == 0 ? __builtin_amdgcn_alignbyte(lo, bl, 3u) : __builtin_amdgcn_alignbyte(hi, lo, sc - 1u);
+                    const uint32_t s1 = __builtin_amdgcn_alignbyte(hi, lo, sc);
+                    const uint32_t s2 = sc == 3 ? hi : __builtin_amdgcn_alignbyte(hi, lo, sc + 1u);
+                    const uint32_t pk_ = p0 + 4 * k;
+                    const uint32_t nv = pk_ < L ? min(L - pk_, 4u) : 0u;
+                    const uint32_t valid = nv >= 4 ? 0x01010101u : ((1u << (8 * nv)) - 1u) & 0x01010101u;
+                    ca[0][k] = __popc(nz_bytes(rd[k] ^ s0) & valid);
+                    ca[1][k] = __popc(nz_bytes(rd[k] ^ s1) & valid);
+                    ca[2][k] = __popc(nz_bytes(rd[k] ^ s2) & valid);
+                }
+                int mm[3];
+#pragma unroll
+                for (int d = 0; d < 3; d++) mm[d] = ca[d][0] + ca[d][1] + ca[d][2] + ca[d][3];
+                decided = (uint32_t)row_sum16(mm[1]) <= ED;
+                if (!decided && ED >= 1 && ED + L + 1 <= W) {
+                    int below[3], above[3];  // counts of the lanes below / above this one
+#pragma unroll
+                    for (int d = 0; d < 3; d++) {
+                        below[d] = row_prefix_incl16(mm[d]) - mm[d];
+                        above[d] = row_suffix_incl16(mm[d]) - mm[d];
+                    }
+                    // first positions on diagonal da, the rest on db, the change inside this lane (after 0 .. 4 groups)
+                    auto split = [&](int da, int db) {
+                        int pa = 0, sb = mm[db], best = mm[db];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            pa += ca[da][k];
+                            sb -= ca[db][k];
+                            best = min(best, pa + sb);
+                        }
+                        return below[da] + best + above[db];
+                    };
+                    int best = min(min(split(1, 0), split(1, 2)), min(split(0, 1), split(2, 1)));
+                    best = -row_max16(-best);
+                    decided = best <= (int)ED - 1;
+                }
+            }
+        }
+        // one entry per group, from its first lane
+        const unsigned long long pm = __ballot(have && gl == 0 && decided), sm = __ballot(have && gl == 0 && !decided);
+        const unsigned long long lower = (1ull << lane) - 1ull;
+        if (have && gl == 0 && decided) pbuf[np + (uint32_t)__popcll(pm & lower)] = gi;
+        if (have && gl == 0 && !decided) sbuf[nsw + (uint32_t)__popcll(sm & lower)] = gi;
+        np += (uint32_t)__popcll(pm);
+        nsw += (uint32_t)__popcll(sm);
+        if (np + 4 > kDiagBuf) flush(pbuf, np, sw_pass_count(a), a.pass_list, 0u);
+        if (nsw + 4 > kDiagBuf) flush(sbuf, nsw, reinterpret_cast<uint32_t*>(a.counters + sweep_slot), sweep_list, kSweepFlag);
+        gi_0 = gi_1;
+        gi_1 = gi_2;
+        gi_2 = gi_3;
+        c_0 = c_1;
+        c_1 = c_2;
+        b0_0 = b0_1;
+        L_0 = L_1;
+    }
+    if (np) flush(pbuf, np, sw_pass_count(a), a.pass_list, 0u);
+    if (nsw) flush(sbuf, nsw, reinterpret_cast<uint32_t*>(a.counters + sweep_slot), sweep_list, kSweepFlag);
+    for (int d = 32; d > 0; d >>= 1) {
+        verified += __shfl_down(verified, d);
+        wbytes += __shfl_down(wbytes, d);
+    }
+    if (lane == 0 && verified) {
+        atomicAdd((unsigned long long*)a.counters + kCtrVerified, verified);
+        atomicAdd((unsigned long long*)a.counters + kCtrWindowBytes, wbytes);
     }
 }
 
@@ -1305,6 +1520,12 @@ void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, 
     else if (max_len <= 208) SW_CASE(13);
     else SW_CASE(16);
 #undef SW_CASE
+}
+
+void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t* sweep_list,
+                    uint32_t sweep_slot) {
+    const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 16), 256 * 8));  // 16 groups per workgroup
+    hipLaunchKernelGGL(k_sw_diag, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
 }
 
 void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len,
