@@ -101,6 +101,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
     if (const char* e = getenv("MTSV_SW_DIAG")) sw_diag = atoi(e) != 0;
     if (const char* e = getenv("MTSV_SW_PREPASS")) sw_prepass = atoi(e) != 0;
+    if (const char* e = getenv("MTSV_SW_TOP")) sw_top = atoi(e) != 0;
     verify_mode = g_default_verify_mode;
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
@@ -228,6 +229,7 @@ void Batch::begin_run(const mtsv_params& p) {
         l->sw_pairs = sw_pairs;
         l->sw_diag = sw_diag;
         l->sw_prepass = sw_prepass;
+        l->sw_top = sw_top;
         l->reset_lane();
     }
 }
@@ -528,6 +530,17 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                         sw.worklist = sweep_list;
                         sw.wl_count_slot = 16;
                         sw.wl_reverse = 0;  // k_sw_diag read the worklist from its end
+                        if (sw_top) {
+                            // most of these are refuted on the top half of the read rows; the full-height launch below
+                            // takes what is left ([17] counts it; the seed-hit rows of k_expand are free by now)
+                            HIP_CHECK(hipMemsetAsync(d_counters + 17, 0, sizeof(uint64_t), stream));
+                            sw.und_list = (uint32_t*)d_hit_row;
+                            sw.und_slot = 17;
+                            launch_sw_pairs(stream, v, sw, items, pass_max_len, false, true);
+                            HIP_CHECK(hipMemsetAsync(d_counters + 8, 0, sizeof(uint64_t), stream));  // the claim cursor
+                            sw.worklist = sw.und_list;
+                            sw.wl_count_slot = 17;
+                        }
                     }
                     launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag);
 #ifdef MTSV_SW_HIST

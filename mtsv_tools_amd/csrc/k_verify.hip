@@ -435,7 +435,7 @@ __device__ inline uint32_t pku_add(uint32_t a, uint32_t b) { return as_bits(as_u
 __device__ inline uint32_t pku_sub(uint32_t a, uint32_t b) { return as_bits(as_u2(a) - as_u2(b)); }
 __device__ inline uint32_t pku_satsub(uint32_t a, uint32_t b) { return as_bits(__builtin_elementwise_sub_sat(as_u2(a), as_u2(b))); }
 
-enum : uint32_t { HF_EMPTY = 0, HF_SWEEP = 1, HF_PASS = 2, HF_FAIL = 3 };
+enum : uint32_t { HF_EMPTY = 0, HF_SWEEP = 1, HF_PASS = 2, HF_FAIL = 3, HF_UNDEC = 4 };
 constexpr uint32_t kSweepFlag = 0x80000000u;  // worklist entry from k_sw_diag: verified/window_bytes counted, bounds tried
 
 // maximum over the 16 lanes of a DPP row, result in every lane: quad swaps, then the two mirrors
@@ -483,16 +483,41 @@ __device__ inline void wave_lds_handoff() {
 __device__ inline uint32_t* sw_cursor(const EvalArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + kCtrSwCursor); }
 __device__ inline uint32_t* sw_pass_count(const EvalArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + kCtrPassCount); }
 
-template <int R, bool DIAG>
+// TOP: the group's 16*R rows are the TOP of a longer read (the launcher halves R).  A candidate without a real
+// alignment -- nearly everything that reaches a sweep once k_sw_diag has run -- is refuted on those rows alone
+// at half the instructions: an alignment that reaches the threshold L - 2*ED starts within the first 2*ED read
+// rows, so it runs through the covered rows and leaves them through the frontier of the sweep (bounded as in
+// the full sweep, with the rows of the whole read below) or through the bottom covered row, where H never
+// exceeded `bot`: bot + (L - 16*R) < threshold refutes the latter.  What the covered rows cannot decide goes to
+// und_list (flagged like k_sw_diag's output) for the full-height launch.  Reads that fit the rows are decided
+// exactly as without TOP.
+template <int R, bool DIAG, bool TOP = false>
 __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
+    static_assert(!(TOP && DIAG), "the bounds on the seed diagonal need the whole read");
     constexpr int GS = 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
     __shared__ uint32_t pend_all[256 / GS][kPend];  // a group's passed candidates, flushed with one atomic per kPend
     __shared__ uint32_t meta_all[256 / GS][kClaim][8];    // the group's claimed work items, staged by its lanes
+    __shared__ uint32_t und_all[TOP ? 256 / GS : 1][TOP ? kPend : 1];  // TOP: a group's undecided candidates
     const uint32_t lane = lane_id();
     const uint32_t gl = lane & (GS - 1);
     uint32_t* pend_buf = pend_all[threadIdx.x / GS];
     uint32_t pend = 0;  // group-uniform
+    uint32_t* und_buf = und_all[TOP ? threadIdx.x / GS : 0];
+    uint32_t und = 0;   // group-uniform
+    auto und_push = [&](uint32_t gq) {
+        if (gl == 0) und_buf[und] = gq | kSweepFlag;
+        und++;
+        if (und == kPend) {
+            uint32_t base = 0;
+            if (gl == 0) base = atomicAdd(reinterpret_cast<uint32_t*>(a.counters + a.und_slot), kPend);
+            base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
+            wave_lds_handoff();
+            for (uint32_t i = gl; i < kPend; i += GS) a.und_list[base + i] = und_buf[i];
+            wave_lds_handoff();
+            und = 0;
+        }
+    };
     // append candidate gq to the pass list (all lanes of the group call it together)
     auto pass_push = [&](uint32_t gq) {
         if (gl == 0) pend_buf[pend] = gq;
@@ -529,6 +554,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
     constexpr uint32_t F_CHAIN = 1u, F_HOPELESS = 4u, F_DRAINED = 16u;
     uint32_t qc2[R];  // read codes << 1, both halves
     uint32_t h[R], up_prev = 0, best = 0;
+    uint32_t bot = 0;  // TOP: largest H of the lane's last row over the swept columns (lane 15: the bottom covered row)
     uint32_t t = 0, steps = 0;
     uint32_t checks = 0;  // next decision point (low 16 bits, saturated) and the scheduled second one (high 16 bits)
     uint32_t verified = 0, wbytes = 0;  // per group: far below 2^32 in one launch
@@ -625,7 +651,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         if (wf & (4u << hf)) {
                             // the lane's rows are R consecutive read bytes (descending for the reverse strand):
                             // aligned dword loads + v_alignbyte; byte k of raw[] is read byte s0 + k
-                            const int pad = (int)(GS * R) - (int)Lh(hf);
+                            const int pad = TOP ? max((int)(GS * R) - (int)Lh(hf), 0) : (int)(GS * R) - (int)Lh(hf);
                             const int p0 = (int)(gl * R) - pad;  // read position of row 0, < 0 for padding rows
                             const int s0 = (strands[hf] & 1u) ? (int)Lh(hf) - 1 - p0 - (R - 1) : p0;
                             const long long byte0 = (long long)b0s[hf] + s0;
@@ -647,7 +673,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                     if (wf & (4u << hf)) {
                         const uint32_t ED = (strands[hf] >> 8) & 0xffu;
                         const bool wrapped = (strands[hf] & 2u) != 0;
-                        const int pad = (int)(GS * R) - (int)Lh(hf);
+                        const int pad = TOP ? max((int)(GS * R) - (int)Lh(hf), 0) : (int)(GS * R) - (int)Lh(hf);
                         int nn = 0;
 #pragma unroll
                         for (int r = 0; r < R; r++) {
@@ -758,6 +784,10 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         if (decided) {
                             pass_push(g[hf]);  // its edit distance is k_edit_myers' business (index.rs:407-410)
                             again = again || !(gf & F_DRAINED);
+                        } else if (TOP && Lq > (uint32_t)(GS * R) && Lq - (uint32_t)(GS * R) >= thrh(hf)) {
+                            // an alignment below the covered rows alone could reach the threshold: nothing to refute here
+                            und_push(g[hf]);
+                            again = again || !(gf & F_DRAINED);
                         } else {
                             st[hf] = HF_SWEEP;
                         }
@@ -773,6 +803,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                 for (int r = 0; r < R; r++) h[r] = 0;
                 up_prev = 0;
                 best = 0;
+                bot = 0;
                 t = 0;
                 steps = max(Wn[0], Wn[1]) + GS - 1;
                 // Decision points: the first where a window without a real alignment typically runs out of
@@ -826,6 +857,11 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                     const uint32_t cl0 = (uint32_t)max((int)Wn[0] - (int)t + (int)gl, 0), cl1 = (uint32_t)max((int)Wn[1] - (int)t + (int)gl, 0);
                     const uint32_t cl = min(cl0, 0xffffu) | (min(cl1, 0xffffu) << 16);
                     uint32_t rl = ((GS - gl) * R - 1) * ONE;
+                    if (TOP) {  // the rows of the whole read below row 0 of this lane: L - 1 - (gl * R - pad), pad = max(16 * R - L, 0)
+                        const int r0_ = (int)Lh(0) - 1 + max((int)(GS * R) - (int)Lh(0), 0) - (int)(gl * R);
+                        const int r1_ = (int)Lh(1) - 1 + max((int)(GS * R) - (int)Lh(1), 0) - (int)(gl * R);
+                        rl = (uint32_t)max(r0_, 0) | ((uint32_t)max(r1_, 0) << 16);
+                    }
                     hb = 0;
 #pragma unroll
                     for (int r = 0; r < R; r++) {
@@ -845,11 +881,19 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                     bmax[hf] = row_max16(bmax[hf]);
                     ub[hf] = row_max16(ub[hf]);
                 }
+                int botv[2] = {0, 0};
+                if (TOP) {
+#pragma unroll
+                    for (int hf = 0; hf < 2; hf++) botv[hf] = row_max16(gl == GS - 1 ? (int)((bot >> (16 * hf)) & 0xffffu) : 0);
+                }
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
                     if (st[hf] == HF_SWEEP) {
                         const int u = max(max(ub[hf], bmax[hf]), (int)Wn[hf] - (int)t + GS);  // or starts in unswept columns
+                        // TOP: what left the covered rows through their last row cannot be refuted any more once H there got too large
+                        const bool open_below = TOP && (int)Lh(hf) > GS * R && botv[hf] + ((int)Lh(hf) - GS * R) >= (int)thrh(hf);
                         if (bmax[hf] >= (int)thrh(hf)) st[hf] = HF_PASS;
+                        else if (open_below) st[hf] = HF_UNDEC;
                         else if (u < (int)thrh(hf) || t >= Wn[hf] + GS - 1) st[hf] = HF_FAIL;
                     }
                 }
@@ -906,6 +950,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                         h[r] = pku_satsub(w, ONE);  // max(w, 1) - 1
                         up = h[r];
                     }
+                    if (TOP) bot = pku_max(bot, up);
                     up_prev = in;
                     t++;
                 }
@@ -927,9 +972,18 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
             for (int hf = 0; hf < 2; hf++) bm[hf] = (int)((best >> (16 * hf)) & 0xffffu) - 1;
             bm[0] = row_max16(bm[0]);
             bm[1] = row_max16(bm[1]);
+            int bv[2] = {0, 0};
+            if (TOP) {
+#pragma unroll
+                for (int hf = 0; hf < 2; hf++) bv[hf] = row_max16(gl == GS - 1 ? (int)((bot >> (16 * hf)) & 0xffffu) : 0);
+            }
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
-                if (st[hf] == HF_SWEEP) st[hf] = bm[hf] >= (int)thrh(hf) ? HF_PASS : HF_FAIL;
+                if (st[hf] == HF_SWEEP) {
+                    const bool open_below = TOP && (int)Lh(hf) > GS * R && bv[hf] + ((int)Lh(hf) - GS * R) >= (int)thrh(hf);
+                    st[hf] = bm[hf] >= (int)thrh(hf) ? HF_PASS : (open_below ? HF_UNDEC : HF_FAIL);
+                }
+                if (TOP && st[hf] == HF_UNDEC) und_push(g[hf]);
 #ifdef MTSV_SW_HIST
                 if (gl == 0 && Wn[hf] != 0) atomicAdd(&reinterpret_cast<uint32_t*>(a.strip)[256 + (st[hf] == HF_PASS ? 256 : 0) + min(max(bm[hf], 0), 255)], 1u);
 #endif
@@ -954,6 +1008,13 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
         wave_lds_handoff();
         for (uint32_t i = gl; i < pend; i += GS) a.pass_list[base + i] = pend_buf[i];
+    }
+    if (TOP && und) {
+        uint32_t base = 0;
+        if (gl == 0) base = atomicAdd(reinterpret_cast<uint32_t*>(a.counters + a.und_slot), und);
+        base = (uint32_t)__shfl((int)base, (int)(lane & ~(uint32_t)(GS - 1)));
+        wave_lds_handoff();
+        for (uint32_t i = gl; i < und; i += GS) a.und_list[base + i] = und_buf[i];
     }
     unsigned long long v64 = gl == 0 ? verified : 0, w64 = gl == 0 ? wbytes : 0, s64 = gl == 0 ? swept : 0;
     for (int d = 32; d > 0; d >>= 1) {
@@ -1501,10 +1562,27 @@ void launch_evaluate_tiled(hipStream_t s, const DevIndexView& ix, const EvalArgs
     hipLaunchKernelGGL((k_evaluate<16, true, 16, true>), dim3(blocks), dim3(256), 0, s, ix, a);
 }
 
-void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len, bool diag) {
+void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len, bool diag, bool top) {
     // persistent 16-lane groups, two candidates per group: one resident generation of blocks pulls the worklist
     EvalArgs a = a_;
     a.maxc = rank_bound(a.max_candidates);
+    if (top) {  // the top half of the rows (a.und_list / a.und_slot take what they cannot decide)
+#define SW_TOP(RR)                                                                                                       \
+    do {                                                                                                                 \
+        const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * kSwOcc));              \
+        a.claim_shift = 0;                                                                                               \
+        while ((1ull << a.claim_shift) < (uint64_t)grid * 16 * 2) a.claim_shift++;                                       \
+        hipLaunchKernelGGL((k_sw_pairs<RR, false, true>), dim3(grid), dim3(256), 0, s, ix, a);                           \
+    } while (0)
+        if (max_len <= 64) SW_TOP(2);
+        else if (max_len <= 96) SW_TOP(3);
+        else if (max_len <= 128) SW_TOP(4);
+        else if (max_len <= 160) SW_TOP(5);
+        else if (max_len <= 208) SW_TOP(7);
+        else SW_TOP(8);
+#undef SW_TOP
+        return;
+    }
 #define SW_CASE(RR)                                                                                                      \
     do {                                                                                                                 \
         const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * ((RR) > 10 ? 3 : kSwOcc))); \

@@ -68,6 +68,8 @@ struct EvalArgs {
     uint32_t* pass_count = nullptr;
     uint32_t* next_list = nullptr;
     uint32_t* next_count = nullptr;
+    uint32_t* und_list = nullptr;  // k_sw_pairs TOP: candidates the covered rows do not decide
+    uint32_t und_slot = 0;
     // tiled long-read kernel: one strip of strip_len window columns per 16-lane group (bottom row of a band)
     uint2* strip = nullptr;
     uint32_t strip_len = 0;
@@ -114,8 +116,10 @@ void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a,
                        bool list_mode = false);
 // reference order for reads <= 253 bases: SW prefilter alone, two candidates per 16-lane group
 // diag = false: without the lower bounds on the seed diagonal (every candidate that is not hopeless is swept)
+// top = true: the sweep on the top half of the read rows (k_sw_pairs<R/2, false, TOP>): refutes or passes what those rows
+// decide, appends the rest to a.und_list (count in the low word of counter slot a.und_slot), flagged, for a second launch
 void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
-                     bool diag = true);
+                     bool diag = true, bool top = false);
 // the prefilter's lower bounds alone, a lane per work item: decided candidates go to a.pass_list (count in kCtrPassCount),
 // the others to sweep_list (count in the low word of counter slot sweep_slot), flagged, for launch_sw_pairs
 void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t* sweep_list,
