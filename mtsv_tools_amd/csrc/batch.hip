@@ -526,7 +526,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     if (round == 0) HIP_CHECK(hipEventRecord(ev[10], stream));
                     if (round == 0 && sw_diag && sw_prepass) {
                         HIP_CHECK(hipMemsetAsync(d_counters + 16, 0, sizeof(uint64_t), stream));
-                        launch_sw_diag(stream, v, sw, items, sweep_list, 16);
+                        launch_sw_diag(stream, v, sw, items, pass_max_len, sweep_list, 16);
                         sw.worklist = sweep_list;
                         sw.wl_count_slot = 16;
                         sw.wl_reverse = 0;  // k_sw_diag read the worklist from its end

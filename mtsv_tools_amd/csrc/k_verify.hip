@@ -1040,7 +1040,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
 // score >= L - 2*ED, the predicate of index.rs:406, without the sweep.  Such a candidate goes to
 // pass_list (k_edit_myers computes its edit distance, :407-410); every other one to sweep_list with
 // bit 31 set, for k_sw_pairs: "counted here, and the bounds do not decide it".
-// Lane gl compares read positions 16*gl .. 16*gl+15 with the three diagonals, four codes per
+// Lane gl compares 8, 12 or 16 read positions (16 lanes cover the longest read of the pass) with the three diagonals, four codes per
 // instruction (mismatch = the codes differ, as in the sweep: N faces N as a match,
 // ssw/src/lib.rs:11-16); the change of diagonal is tried after every fourth read position, both
 // orders of every adjacent pair (prefix counts of the lanes below + the best split inside the lane +
@@ -1068,6 +1068,8 @@ __device__ inline int row_suffix_incl16(int v) {
 
 constexpr uint32_t kDiagBuf = 128;  // decisions a wavefront of k_sw_diag buffers per list
 
+// NW: words of four read positions per lane (16 * 4 * NW >= the longest read of the pass)
+template <int NW>
 __global__ __launch_bounds__(256) void k_sw_diag(DevIndexView ix, EvalArgs a, uint32_t* __restrict__ sweep_list, uint32_t sweep_slot) {
     __shared__ uint32_t buf_all[256 / kWave][2][kDiagBuf];
     uint32_t* pbuf = buf_all[threadIdx.x / kWave][0];
@@ -1140,38 +1142,38 @@ __global__ __launch_bounds__(256) void k_sw_diag(DevIndexView ix, EvalArgs a, ui
                 wbytes += W;
             }
             if (2ull * ED <= (uint64_t)L && ED + L <= W) {
-                const uint32_t p0 = gl * 16;  // this lane's first read position
-                // read codes of positions p0 .. p0+15 (reverse strand: the complement of bytes b0+L-1-p0 downwards)
-                uint32_t rd[4];
+                const uint32_t p0 = gl * (4 * NW);  // this lane's first read position
+                // read codes of positions p0 .. p0+4*NW-1 (reverse strand: the complement of bytes b0+L-1-p0 downwards)
+                uint32_t rd[NW];
                 {
                     const bool rev = (rs & 1u) != 0;
                     // (lanes past the read compare nothing: they load the read's first bytes instead of running off the buffer;
                     //  word indices below 0 -- the tail of a reverse strand at the buffer's start -- are clamped, those bytes are masked)
                     const uint32_t pq = p0 < L ? p0 : 0u;
-                    const long long ba = rev ? (long long)b0 + L - 16 - pq : (long long)b0 + pq;
+                    const long long ba = rev ? (long long)b0 + L - 4 * NW - pq : (long long)b0 + pq;
                     const long long w = ba >> 2;
                     const uint32_t sh = (uint32_t)(ba & 3);
-                    uint32_t d[5];
+                    uint32_t d[NW + 1];
 #pragma unroll
-                    for (int k = 0; k < 5; k++) d[k] = b32[max(w + k, 0ll)];  // (the buffer is padded past its end)
-                    uint32_t x[4];
+                    for (int k = 0; k <= NW; k++) d[k] = b32[max(w + k, 0ll)];  // (the buffer is padded past its end)
+                    uint32_t x[NW];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) x[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
+                    for (int k = 0; k < NW; k++) x[k] = __builtin_amdgcn_alignbyte(d[k + 1], d[k], sh);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) rd[k] = rev ? comp_codes4(__builtin_bswap32(x[3 - k])) : x[k];
+                    for (int k = 0; k < NW; k++) rd[k] = rev ? comp_codes4(__builtin_bswap32(x[NW - 1 - k])) : x[k];
                 }
-                // window bytes pc - 1 .. pc + 16 around the middle diagonal (byte pc + j faces read position p0 + j)
+                // window bytes pc - 1 .. pc + 4*NW around the middle diagonal (byte pc + j faces read position p0 + j)
                 const uint32_t pc = c.x + ED + p0;
                 const uint32_t wi = pc >> 2, sc = pc & 3u;
-                uint32_t wv[6];  // words wi - 1 .. wi + 4
+                uint32_t wv[NW + 2];  // words wi - 1 .. wi + NW
                 // (clamped, not guarded: every byte a valid position compares lies inside the window, hence inside the text;
                 //  the byte before position 0 is only wrong when c.x + ED = 0, where the gap bound -- ED >= 1 -- is not tried)
                 wv[0] = t32[wi >= 1 ? min(wi - 1, lastw) : 0u];
 #pragma unroll
-                for (int k = 0; k < 5; k++) wv[k + 1] = t32[min(wi + k, lastw)];
-                int ca[3][4];  // mismatches per diagonal and group of four positions
+                for (int k = 0; k <= NW; k++) wv[k + 1] = t32[min(wi + k, lastw)];
+                int ca[3][NW];  // mismatches per diagonal and word of four positions
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
+                for (int k = 0; k < NW; k++) {
                     const uint32_t lo = wv[k + 1], hi = wv[k + 2], bl = wv[k];
                     const uint32_t s0 = sc == 0 ? __builtin_amdgcn_alignbyte(lo, bl, 3u) : __builtin_amdgcn_alignbyte(hi, lo, sc - 1u);
                     const uint32_t s1 = __builtin_amdgcn_alignbyte(hi, lo, sc);
@@ -1185,7 +1187,11 @@ __global__ __launch_bounds__(256) void k_sw_diag(DevIndexView ix, EvalArgs a, ui
                 }
                 int mm[3];
 #pragma unroll
-                for (int d = 0; d < 3; d++) mm[d] = ca[d][0] + ca[d][1] + ca[d][2] + ca[d][3];
+                for (int d = 0; d < 3; d++) {
+                    mm[d] = 0;
+#pragma unroll
+                    for (int k = 0; k < NW; k++) mm[d] += ca[d][k];
+                }
                 decided = (uint32_t)row_sum16(mm[1]) <= ED;
                 if (!decided && ED >= 1 && ED + L + 1 <= W) {
                     int below[3], above[3];  // counts of the lanes below / above this one
@@ -1194,11 +1200,11 @@ __global__ __launch_bounds__(256) void k_sw_diag(DevIndexView ix, EvalArgs a, ui
                         below[d] = row_prefix_incl16(mm[d]) - mm[d];
                         above[d] = row_suffix_incl16(mm[d]) - mm[d];
                     }
-                    // first positions on diagonal da, the rest on db, the change inside this lane (after 0 .. 4 groups)
+                    // first positions on diagonal da, the rest on db, the change inside this lane (after 0 .. NW words)
                     auto split = [&](int da, int db) {
                         int pa = 0, sb = mm[db], best = mm[db];
 #pragma unroll
-                        for (int k = 0; k < 4; k++) {
+                        for (int k = 0; k < NW; k++) {
                             pa += ca[da][k];
                             sb -= ca[db][k];
                             best = min(best, pa + sb);
@@ -1600,10 +1606,12 @@ void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, 
 #undef SW_CASE
 }
 
-void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t* sweep_list,
-                    uint32_t sweep_slot) {
+void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
+                    uint32_t* sweep_list, uint32_t sweep_slot) {
     const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 16), 256 * 8));  // 16 groups per workgroup
-    hipLaunchKernelGGL(k_sw_diag, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
+    if (max_len <= 128) hipLaunchKernelGGL(k_sw_diag<2>, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
+    else if (max_len <= 192) hipLaunchKernelGGL(k_sw_diag<3>, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
+    else hipLaunchKernelGGL(k_sw_diag<4>, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
 }
 
 void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len,

@@ -122,8 +122,8 @@ void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, u
                      bool diag = true, bool top = false);
 // the prefilter's lower bounds alone, a lane per work item: decided candidates go to a.pass_list (count in kCtrPassCount),
 // the others to sweep_list (count in the low word of counter slot sweep_slot), flagged, for launch_sw_pairs
-void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t* sweep_list,
-                    uint32_t sweep_slot);
+void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
+                    uint32_t* sweep_list, uint32_t sweep_slot);
 void launch_resolve(hipStream_t s, uint32_t n_strands, int64_t max_candidates, int64_t max_assignments,
                     const uint32_t* strand_off, const uint32_t* strand_ncand, const uint32_t* cand_status, uint4* out,
                     uint32_t* strand_nout);

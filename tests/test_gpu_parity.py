@@ -573,6 +573,36 @@ def test_lanes_do_not_change_hits_or_counters(medium, monkeypatch):
         b.close()
 
 
+def test_prefilter_stages_decide_alike(medium, tricky, monkeypatch):
+    """The SW prefilter of index.rs:406 runs as three kernels in the first round of a pass -- the bounds on the seed
+    diagonal (k_sw_diag), the sweep on the top half of the read rows (k_sw_pairs TOP), the full-height sweep of
+    what is left -- or, with the environment switches below, as two or as one.  Every arrangement decides every
+    candidate alike: same hits, same candidates examined, same number sent on to the edit distance."""
+    ix, bases, off = medium
+    tix, _, treads = tricky
+    tb, to = helpers.reads_to_batch([r for r in treads if len(r) <= 253])
+    ref = {}
+    for prepass, top in (("0", "0"), ("1", "0"), ("1", "1")):
+        monkeypatch.setenv("MTSV_SW_PREPASS", prepass)
+        monkeypatch.setenv("MTSV_SW_TOP", top)
+        for name, (x, b_, o_) in (("medium", (ix, bases, off)), ("tricky", (tix, tb, to))):
+            x.to_device(0)
+            b = M.Batch(x, 0, len(o_) - 1, len(b_))
+            b.upload(b_, o_)
+            b.run()
+            st = b.stats()
+            got = (b.download(), {k: st[k] for k in ("n_candidates", "n_verified", "window_bytes", "n_sw_passed", "n_hits")})
+            b.close()
+            if name not in ref:
+                ref[name] = got
+                assert got[1]["n_sw_passed"] >= got[1]["n_hits"] > 0
+            assert_same_hits(got[0], ref[name][0])
+            assert got[1] == ref[name][1], (name, prepass, top)
+            if (prepass, top) == ("1", "1"):
+                # the top-half sweep computes about half the cells of the full-height one (both count theirs)
+                assert 0 < st["sw_cell_pairs"]
+
+
 def test_run_host_recycles_the_lanes_result_arrays(medium, monkeypatch):
     """a host batch far larger than the workspace: every lane's device result array is reused once its hits have
     left for the host (tiny arrays here: dozens of wrap-arounds per lane), growth still works for a slice that
