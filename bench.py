@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--resident-only", action="store_true",
                     help="profiling mode: upload the reads once and time K resident runs (mtsv_batch_run) only -- every launch in the "
                          "process then belongs to a whole-batch pipeline pass (tools/profile_round.sh); the line is marked as such")
+    ap.add_argument("--pageable-input", action="store_true",
+                    help="time the steps on reads in ordinary (pageable) host memory instead of memory from mtsv_host_alloc")
     ap.add_argument("--verify-mode", type=int, default=0, help="0: reference order (SW + edit per candidate), 1: edit first")
     ap.add_argument("--dev-flags", type=int, default=0, help="MTSV_DEV_* flags (1: sampled SA only, 2: no k-mer table)")
     args = ap.parse_args()
@@ -200,7 +202,15 @@ def main():
     slice_reads = int(os.environ.get("MTSV_BENCH_SLICE", 0)) or M.bin_batch_slice_reads(n_reads)
     hb = M.Batch(ix, local_rank, min(n_reads, slice_reads), min(len(bases), slice_reads * (read_len + 8)))
     hb.set_verify_mode(args.verify_mode)
-    bases_p, off_p = bases.ctypes.data, off.ctypes.data
+    # The reads of the timed steps lie in host memory from the library's allocator (mtsv_host_alloc: page-locked, what a
+    # host integrating the library parses its reads into -- INTEGRATION.md): the copy engine reads them in place.  The
+    # same steps on an ordinary numpy array (staged through the library's own page-locked buffers) are timed after
+    # the headline steps and reported as `pageable_input`.
+    pinned = None
+    if not args.pageable_input:
+        pinned = M.HostBuffer(len(bases))
+        pinned.array[:] = bases
+    bases_p, off_p = (pinned.array if pinned else bases).ctypes.data, off.ctypes.data
 
     split = [0.0, 0.0, 0.0]  # seconds inside mtsv_batch_run_host / mtsv_batch_download / mtsv_hits_free over the timed steps
 
@@ -226,8 +236,11 @@ def main():
     split[:] = [0.0, 0.0, 0.0]
     t0 = time.perf_counter()
     host_stage = None
+    each_ms = []
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         host_step()
+        each_ms.append(round((time.perf_counter() - t_s) * 1e3, 2))
         sth = hb.stats()
         if host_stage is None:
             host_stage = dict(sth["stage_ms"])
@@ -242,7 +255,23 @@ def main():
         elapsed = float(t.item())
     st_host = hb.stats()
     hits = host_step(keep=True)  # untimed: the hits the parity checks below look at
+    pageable = None
+    if pinned is not None and not args.no_extras and rank == 0:
+        bases_p = bases.ctypes.data
+        host_step()
+        t1 = time.perf_counter()
+        for _ in range(3):
+            host_step()
+        pg_dt = (time.perf_counter() - t1) / 3
+        pageable = {"reads_per_s": n_reads / pg_dt, "ms_per_step": pg_dt * 1e3,
+                    "note": "the same step on reads in an ordinary numpy array (3 runs after 1 warm-up): one more host memcpy per slice"}
+        hits_pg = host_step(keep=True)
+        if not same_hits(hits_pg, hits):
+            raise SystemExit("bench: page-locked and pageable input returned different hits")
+        del hits_pg
     hb.close()
+    if pinned is not None:
+        pinned.close()
 
     if rank != 0:
         if world > 1:
@@ -413,7 +442,10 @@ def main():
                         "index load/upload excluded",
         "timed_calls_ms_per_step": {"mtsv_batch_run_host": split[0] / args.steps * 1e3, "mtsv_batch_download": split[1] / args.steps * 1e3,
                                     "mtsv_hits_free": split[2] / args.steps * 1e3},
+        "step_ms_each": each_ms,
         "device_resident": resident,
+        "host_input": "ordinary (pageable) memory" if args.pageable_input else "page-locked memory from mtsv_host_alloc",
+        "pageable_input": pageable,
         "config": {"workload": f"{args.workload}: {desc}", "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                    "index_symbols": info["n"], "index_file_bytes": os.path.getsize(idx_path),
                    "index_hbm_bytes": info["device_bytes"], "dev_flags": args.dev_flags, "workspace_reads": min(n_reads, slice_reads),

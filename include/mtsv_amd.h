@@ -146,6 +146,17 @@ int mtsv_index_to_device(mtsv_index *ix, int hip_device, uint32_t flags);
 int mtsv_bin_batch(mtsv_index *ix, int hip_device, const uint8_t *bases, const uint64_t *read_off,
                    uint64_t n_reads, const mtsv_params *params, mtsv_hit **hits, uint64_t *n_hits);
 void mtsv_hits_free(mtsv_hit *hits);
+/* Page-locked host memory for read buffers (the reference fills plain Vec<u8> buffers, src/binner.rs:21-66; a host
+ * that keeps its parsed reads in memory from here spares every call a copy).  mtsv_bin_batch*, mtsv_batch_upload and
+ * mtsv_batch_run_host recognise bases that lie in such memory and let the GPU's copy engine read them where they
+ * are; any other memory is staged through the library's own page-locked buffers first (a host memcpy per slice).
+ * mtsv_host_register page-locks memory the caller already owns (page-aligned ranges are best; it must be
+ * unregistered before it is freed).  Both work without an index or a batch; NULL / an error code when no HIP
+ * device is usable. */
+void *mtsv_host_alloc(size_t bytes);
+void mtsv_host_free(void *p);
+int mtsv_host_register(void *p, size_t bytes);
+int mtsv_host_unregister(void *p);
 /* ---- several GPUs of one node (no collective: reads are independent) --------
  * Mode A -- the reference's single-index workflow (README.md:69-73) on several GPUs: the index is replicated
  * on every listed device, the reads are cut into n_devices contiguous blocks, one host thread and workspace per

@@ -8,6 +8,9 @@ when the library or a device is missing.
 """
 from ._lib import (  # noqa: F401
     HIT_DTYPE,
+    HostBuffer,
+    host_register,
+    host_unregister,
     Batch,
     MGIndex,
     MtsvError,

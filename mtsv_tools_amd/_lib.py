@@ -63,6 +63,7 @@ EXPORTS = [
     "mtsv_batch_stats_get", "mtsv_batch_set_verify_mode", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads", "mtsv_bin_batch_workspace_reads",
     "mtsv_bin_batch_multi", "mtsv_bin_batch_chunks", "mtsv_set_default_verify_mode",
+    "mtsv_host_alloc", "mtsv_host_free", "mtsv_host_register", "mtsv_host_unregister",
 ]
 
 _lib = None
@@ -112,6 +113,12 @@ def lib():
         L.mtsv_free.restype = None
         L.mtsv_synth_index.argtypes = [u64, u32, u32, u64, u32, u64, i32, C.POINTER(vp)]
         L.mtsv_synth_reads.argtypes = [vp, u64, u64, u32, vp, vp]
+        L.mtsv_host_alloc.argtypes = [C.c_size_t]
+        L.mtsv_host_alloc.restype = vp
+        L.mtsv_host_free.argtypes = [vp]
+        L.mtsv_host_free.restype = None
+        L.mtsv_host_register.argtypes = [vp, C.c_size_t]
+        L.mtsv_host_unregister.argtypes = [vp]
         _lib = L
     return _lib
 
@@ -152,6 +159,31 @@ def bin_batch_chunks(indexes, devices, bases, read_off, params=None):
     _check(lib().mtsv_bin_batch_chunks(hs, dev, len(indexes), bases.ctypes.data, read_off.ctypes.data,
                                        len(read_off) - 1, C.byref(params), C.byref(out), C.byref(n)))
     return _hits_from(out, n.value)
+
+
+class HostBuffer:
+    """mtsv_host_alloc: page-locked host memory as a uint8 numpy array (`.array`); free with close()"""
+
+    def __init__(self, nbytes):
+        self.ptr = lib().mtsv_host_alloc(nbytes)
+        if not self.ptr:
+            raise MtsvError(E_DEVICE, lib().mtsv_last_error().decode(errors="replace"))
+        self.array = np.ctypeslib.as_array((C.c_uint8 * max(1, nbytes)).from_address(self.ptr))[:nbytes]
+
+    def close(self):
+        if self.ptr:
+            self.array = None
+            lib().mtsv_host_free(self.ptr)
+            self.ptr = None
+
+
+def host_register(arr):
+    """page-lock the memory of a contiguous numpy array in place (mtsv_host_register); undo with host_unregister"""
+    _check(lib().mtsv_host_register(arr.ctypes.data, arr.nbytes))
+
+
+def host_unregister(arr):
+    _check(lib().mtsv_host_unregister(arr.ctypes.data))
 
 
 def bin_batch_slice_reads(n_reads):

@@ -52,6 +52,44 @@ void dev_alloc(T** p, uint64_t count, uint64_t* bytes) {
 }
 }  // namespace
 
+// true when [p, p + bytes) is page-locked host memory the runtime knows (hipHostMalloc / hipHostRegister)
+bool host_pinned(const void* p, uint64_t bytes) {
+    if (!p || !bytes) return false;
+    for (const uint8_t* q : {(const uint8_t*)p, (const uint8_t*)p + bytes - 1}) {
+        hipPointerAttribute_t at;
+        memset(&at, 0, sizeof at);
+        if (hipPointerGetAttributes(&at, q) != hipSuccess) {
+            (void)hipGetLastError();  // ordinary memory: not an error of ours
+            return false;
+        }
+        if (at.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+void* host_pinned_alloc(uint64_t bytes) {
+    void* p = nullptr;
+    if (hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    return p;
+}
+void host_pinned_free(void* p) {
+    if (p && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
+bool host_pinned_register(void* p, uint64_t bytes) {
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+bool host_pinned_unregister(void* p) {
+    if (hipHostUnregister(p) == hipSuccess) return true;
+    (void)hipGetLastError();
+    return false;
+}
+
+
 int g_default_verify_mode = MTSV_VERIFY_REFERENCE;
 
 constexpr uint64_t kLaneMinReads = 32768;  // a lane below this many reads does not fill the device
@@ -153,6 +191,7 @@ void Batch::alloc_hit_workspace() {
 }
 
 void Batch::grow_hit_workspace(uint64_t need) {
+    if (getenv("MTSV_TRACE")) fprintf(stderr, "[workspace] seed-hit arrays grow %llu -> %llu entries\n", (unsigned long long)hit_cap, (unsigned long long)need);
     HIP_CHECK(hipStreamSynchronize(stream));
     for (void* p : {(void*)d_hit_row, (void*)d_hit_ref, (void*)d_hit_q, (void*)d_hit_key, (void*)d_cand_tmp, (void*)d_cand,
                     (void*)d_out, (void*)d_cand_next, (void*)d_cand_status, (void*)d_worklist})
@@ -399,6 +438,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             // towards the workspace size, and every hipFree / hipMalloc stalls the whole device
             const uint64_t want = tiled ? slots : std::max<uint64_t>(slots, 2 * ws_reads * (uint64_t)max_ns);
             uint64_t dummy = 0;
+            if (getenv("MTSV_TRACE")) fprintf(stderr, "[workspace] seed slot arrays grow %llu -> %llu entries\n", (unsigned long long)seed_cap, (unsigned long long)want);
             dev_alloc(&d_seed_lo, want, &dummy);
             dev_alloc(&d_seed_cnt, want, &dummy);
             dev_alloc(&d_seed_pre, want, &dummy);
@@ -720,6 +760,9 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
         HIP_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
     }
     const bool trace = getenv("MTSV_TRACE") != nullptr;
+    // bases in page-locked memory (mtsv_host_alloc / mtsv_host_register) go to the GPU from where they lie
+    const bool direct = n && host_pinned(bases, read_off[n]) && !getenv("MTSV_STAGE_ALWAYS");
+    if (trace) fprintf(stderr, "[run_host] input %s\n", direct ? "page-locked: copied from the caller's buffer" : "pageable: staged");
     struct Slice {
         uint64_t begin = 0, end = 0;
         uint32_t max_len = 0;
@@ -750,12 +793,16 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
 
     n_reads = n;
     max_len = 0;
+    if (trace) fprintf(stderr, "[run_host] entered; begin_run at %.2f ms\n", (now_s() - t_entry) * 1e3);
     begin_run(p);
     staged_hits = 0;
     if (!h_hits_stage) {
         // expect about as many hits as the last run produced (first run: one per read)
-        h_hits_stage = pinned_hits_alloc(std::max<uint64_t>(last_total_hits + last_total_hits / 8, std::min<uint64_t>(n, 1ull << 22)), &h_hits_cap);
+        // (a fresh page-locked array costs ~60 us per MB to create and is slow on its first copy: ask for little more than
+        //  the last batch needed, so that the array that batch returned to the pool fits again)
+        h_hits_stage = pinned_hits_alloc(last_total_hits ? last_total_hits + last_total_hits / 64 : n + n / 8, &h_hits_cap);
     }
+    if (trace) fprintf(stderr, "[run_host] result array of %llu hits ready at %.2f ms\n", (unsigned long long)h_hits_cap, (now_s() - t_entry) * 1e3);
 
     // ---- uploaders ----
     auto uploader = [&](int tid) {
@@ -816,8 +863,8 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                 }
                 const double t0 = now_s();
                 if (nb) {
-                    parallel_copy(rb.h_bases, bases + first, nb);
-                    HIP_CHECK(hipMemcpyAsync(rb.d_bases, rb.h_bases, nb, hipMemcpyHostToDevice, cs));
+                    if (!direct) parallel_copy(rb.h_bases, bases + first, nb);
+                    HIP_CHECK(hipMemcpyAsync(rb.d_bases, direct ? bases + first : rb.h_bases, nb, hipMemcpyHostToDevice, cs));
                 }
                 HIP_CHECK(hipMemcpyAsync(rb.d_off, rb.h_off, (cnt + 1) * 4, hipMemcpyHostToDevice, cs));
                 const double t1 = now_s();
@@ -925,6 +972,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
 // pinned result array of run_host: grown geometrically through the pool (mu of run_host held)
 void Batch::stage_reserve(uint64_t n_hits_needed) {
     if (n_hits_needed <= h_hits_cap) return;
+    if (getenv("MTSV_TRACE")) fprintf(stderr, "[run_host] result array grows %llu -> %llu hits\n", (unsigned long long)h_hits_cap, (unsigned long long)n_hits_needed);
     HIP_CHECK(hipStreamSynchronize(copy_stream2));
     uint64_t ncap = 0;
     mtsv_hit* nh = pinned_hits_alloc(std::max<uint64_t>(2 * h_hits_cap, n_hits_needed), &ncap);

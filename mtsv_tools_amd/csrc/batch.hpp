@@ -111,6 +111,12 @@ extern int g_default_verify_mode;  // mtsv_set_default_verify_mode
 // result arrays in pinned host memory, recycled through a pool (mtsv_hits_free returns them)
 mtsv_hit* pinned_hits_alloc(uint64_t n_hits, uint64_t* cap_hits);
 bool pinned_hits_release(void* p);  // false: p is not a pool array
+// page-locked host memory for the callers' read buffers (mtsv_host_alloc & co.)
+void* host_pinned_alloc(uint64_t bytes);
+void host_pinned_free(void* p);
+bool host_pinned_register(void* p, uint64_t bytes);
+bool host_pinned_unregister(void* p);
+bool host_pinned(const void* p, uint64_t bytes);
 
 }  // namespace mtsv
 

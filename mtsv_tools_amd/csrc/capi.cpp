@@ -416,6 +416,29 @@ void mtsv_hits_free(mtsv_hit* hits) {
 }
 void mtsv_free(void* p) { free(p); }
 
+void* mtsv_host_alloc(size_t bytes) {
+    void* p = mtsv::host_pinned_alloc(bytes);
+    if (!p) g_err = "device: page-locked allocation of " + std::to_string(bytes) + " bytes failed (no HIP device?)";
+    return p;
+}
+void mtsv_host_free(void* p) { mtsv::host_pinned_free(p); }
+int mtsv_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return fail_arg("null argument");
+    if (!mtsv::host_pinned_register(p, bytes)) {
+        g_err = "device: the memory could not be page-locked (no HIP device, or the range is already registered)";
+        return MTSV_E_DEVICE;
+    }
+    return MTSV_OK;
+}
+int mtsv_host_unregister(void* p) {
+    if (!p) return fail_arg("null argument");
+    if (!mtsv::host_pinned_unregister(p)) {
+        g_err = "device: not a registered range";
+        return MTSV_E_DEVICE;
+    }
+    return MTSV_OK;
+}
+
 // ---- write_assignments (src/binner.rs:310-379) ------------------------------------------------
 int mtsv_format_results(const mtsv_hit* hits, uint64_t n_hits, const char* ids, const uint64_t* id_off, uint64_t n_reads,
                         int long_format, char** out, uint64_t* out_len) {

@@ -603,6 +603,30 @@ def test_prefilter_stages_decide_alike(medium, tricky, monkeypatch):
                 assert 0 < st["sw_cell_pairs"]
 
 
+def test_page_locked_input_is_read_in_place(medium, capfd, monkeypatch):
+    """bases in memory from mtsv_host_alloc, or registered with mtsv_host_register, skip the staging copy of
+    run_host (MTSV_TRACE names the route); the hits do not depend on where the bases lie"""
+    ix, bases, off = medium
+    ix.to_device(0)
+    want = ix.bin_batch(bases, off, device=0)
+    monkeypatch.setenv("MTSV_TRACE", "1")
+    hb = M.HostBuffer(len(bases))
+    hb.array[:] = bases
+    capfd.readouterr()
+    assert_same_hits(ix.bin_batch(hb.array, off, device=0), want)
+    assert "page-locked" in capfd.readouterr().err
+    hb.close()
+    own = bases.copy()
+    assert_same_hits(ix.bin_batch(own, off, device=0), want)
+    assert "pageable" in capfd.readouterr().err
+    M.host_register(own)
+    assert_same_hits(ix.bin_batch(own, off, device=0), want)
+    assert "page-locked" in capfd.readouterr().err
+    M.host_unregister(own)
+    with pytest.raises(M.MtsvError):
+        M.host_unregister(own)
+
+
 def test_run_host_recycles_the_lanes_result_arrays(medium, monkeypatch):
     """a host batch far larger than the workspace: every lane's device result array is reused once its hits have
     left for the host (tiny arrays here: dozens of wrap-arounds per lane), growth still works for a slice that
