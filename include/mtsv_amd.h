@@ -103,6 +103,8 @@ typedef struct {
                              * 7-instruction recurrence each; 4 groups share a wave instruction) */
     float sw_prefilter_ms;  /* device time of the k_sw_pairs launches (HIP events on the lane's stream), summed
                              * over lanes like stage_ms; part of stage_ms[5] */
+    float sw_sweep_ms;      /* of that, the sweeps (k_sw_pairs on the top half of the rows + at full height); the rest of
+                             * sw_prefilter_ms is k_sw_diag, the bounds on the seed diagonal */
     uint64_t n_sw_passed;   /* candidates whose SW score reached the threshold of index.rs:406, i.e. the edit
                              * distances the reference computes (:407-409).  Counted where the prefilter is a
                              * kernel of its own (reference order, reads up to 253 bases); 0 otherwise */

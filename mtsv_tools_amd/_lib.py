@@ -42,7 +42,7 @@ class BatchStats(C.Structure):  # mtsv_batch_stats
                 ("n_candidates", C.c_uint64), ("n_verified", C.c_uint64),
                 ("window_bytes", C.c_uint64), ("n_hits", C.c_uint64), ("n_passes", C.c_uint64),
                 ("n_rounds", C.c_uint64), ("n_lanes", C.c_uint64), ("sw_cell_pairs", C.c_uint64), ("sw_prefilter_ms", C.c_float),
-                ("n_sw_passed", C.c_uint64)]
+                ("sw_sweep_ms", C.c_float), ("n_sw_passed", C.c_uint64)]
 
     def as_dict(self):
         d = {n: (float(getattr(self, n)) if t is C.c_float else int(getattr(self, n))) for n, t in self._fields_[1:]}

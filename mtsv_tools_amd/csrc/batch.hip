@@ -233,6 +233,7 @@ void Batch::reset_lane() {
     memset(&stats, 0, sizeof stats);
     memset(stage_acc, 0, sizeof stage_acc);
     sw_ms_acc = 0;
+    sweep_ms_acc = 0;
     sw_passed_acc = 0;
     n_hits_total = 0;
     HIP_CHECK(hipMemsetAsync(d_counters, 0, kCounters * sizeof(uint64_t), stream));
@@ -246,6 +247,7 @@ void Batch::finish_lane() {
     HIP_CHECK(hipEventElapsedTime(&stage_acc[7], ev[8], ev[9]));
     stats.sw_cell_pairs = h_counters[14];
     stats.sw_prefilter_ms = sw_ms_acc;
+    stats.sw_sweep_ms = sweep_ms_acc;
     stats.n_sw_passed = sw_passed_acc;
     stats.lf_steps = h_counters[2];
     stats.n_candidates = h_counters[3];
@@ -294,6 +296,7 @@ void Batch::end_run() {
         stats.window_bytes += l->stats.window_bytes;
         stats.sw_cell_pairs += l->stats.sw_cell_pairs;
         stats.sw_prefilter_ms += l->stats.sw_prefilter_ms;
+        stats.sw_sweep_ms += l->stats.sw_sweep_ms;
         stats.n_sw_passed += l->stats.n_sw_passed;
     }
     if (overlapped) stage_acc[7] = (float)wall_ms;
@@ -567,6 +570,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     if (round == 0 && sw_diag && sw_prepass) {
                         HIP_CHECK(hipMemsetAsync(d_counters + 16, 0, sizeof(uint64_t), stream));
                         launch_sw_diag(stream, v, sw, items, pass_max_len, sweep_list, 16);
+                        HIP_CHECK(hipEventRecord(ev[12], stream));
                         sw.worklist = sweep_list;
                         sw.wl_count_slot = 16;
                         sw.wl_reverse = 0;  // k_sw_diag read the worklist from its end
@@ -613,6 +617,8 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                         float ms = 0;
                         HIP_CHECK(hipEventElapsedTime(&ms, ev[10], ev[11]));
                         sw_ms_acc += ms;
+                        if (sw_diag && sw_prepass) HIP_CHECK(hipEventElapsedTime(&ms, ev[12], ev[11]));
+                        sweep_ms_acc += ms;
                     }
                     const uint64_t n_next = h_counters[11] & 0xffffffffull;
                     if (n_next == 0) break;

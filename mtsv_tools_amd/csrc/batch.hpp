@@ -64,8 +64,8 @@ struct Batch {
     uint2* d_strip = nullptr;  // tiled long-read kernel: band hand-over strips, allocated when a pass first needs them
     uint64_t strip_cap = 0;
     uint64_t* h_counters = nullptr;  // pinned
-    hipEvent_t ev[12];  // [0..7] stage boundaries of a pass, [8..9] the lane's run, [10..11] around k_sw_pairs
-    float sw_ms_acc = 0;
+    hipEvent_t ev[13];  // [0..7] stage boundaries of a pass, [8..9] the lane's run, [10..11] around the prefilter kernels, [12] after k_sw_diag
+    float sw_ms_acc = 0, sweep_ms_acc = 0;
     uint64_t sw_passed_acc = 0;   // candidates k_sw_pairs sent on to the edit distance (all rounds and passes of the run)
 
     std::vector<uint32_t> h_read_off;
