@@ -83,12 +83,13 @@ __global__ void k_kmer_level1(DevIndexView ix, uint2* __restrict__ tab) {
 
 // level j from level j-1: interval(aP) = LF-step(a, interval(P)); index(aP) = a*4^(j-1)+index(P)
 __global__ void k_kmer_level(DevIndexView ix, const uint2* __restrict__ prev, uint2* __restrict__ cur,
-                             uint32_t prev_entries) {
-    // grid-stride: the last level of a 16-mer table has 2^32 entries, more than one launch may have threads
-    const uint64_t total = (uint64_t)prev_entries * 4, stride = (uint64_t)gridDim.x * blockDim.x;
+                             uint32_t prev_shift) {
+    // grid-stride: the last level of a 16-mer table has 2^32 entries (of a 17-mer table 2^34), more than one launch may have threads;
+    // the level below has 4^(j-1) = 2^prev_shift entries
+    const uint64_t total = 4ull << prev_shift, stride = (uint64_t)gridDim.x * blockDim.x;
     for (uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += stride) {
-        uint32_t a = (uint32_t)(t / prev_entries);
-        uint32_t p = (uint32_t)(t % prev_entries);
+        uint32_t a = (uint32_t)(t >> prev_shift);
+        uint64_t p = t & ((1ull << prev_shift) - 1);
         uint2 iv = prev[p];
         uint32_t lo = 0, hi = 0;
         if (iv.x < iv.y) {
@@ -287,17 +288,22 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
         v.sa_full = di->d_sa_full;
     }
     if (!(flags & 2u /* MTSV_DEV_NO_KMER_TABLE */)) {
-        // table size ~ index size: 4^k entries of 8 B for 4^k <= 2n, at most k = 16 (32 GiB: every symbol of the
-        // table saves a dependent pair of rank-block gathers per seed), and only if it fits the free HBM twice over
+        // table size ~ index size: 4^k entries of 8 B for 4^k <= 2n up to k = 16 (32 GiB: every symbol of the
+        // table saves a dependent pair of rank-block gathers per seed), and only if it fits the free HBM twice over.
+        // Indexes of 2^31 symbols or more get a 17th symbol (128 GiB) when the device has the room: that is what
+        // 288 GB of HBM are for -- the 10 GB index then costs 153 GB and a default seed of 18 symbols one rank step.
         uint32_t k = 1;
         while (k < 16 && (1ull << (2 * (k + 1))) <= 2 * (uint64_t)n) k++;
+        if (k == 16 && n >= (1u << 31)) k = 17;
         if (const char* e = getenv("MTSV_KMER_K")) {
             int kk = atoi(e);
-            if (kk >= 1 && kk <= 16) k = (uint32_t)kk;
+            if (kk >= 1 && kk <= 17) k = (uint32_t)kk;
         }
         size_t free_b = 0, total_b = 0;
         HIP_CHECK(hipMemGetInfo(&free_b, &total_b));
-        while (k > 1 && (10ull << (2 * k)) * 2 > (uint64_t)free_b) k--;  // table + the previous level while building
+        // 17: the table, the level below it while building, and 48 GiB left for batch workspaces
+        if (k == 17 && (10ull << 34) + (48ull << 30) > (uint64_t)free_b) k = 16;
+        while (k > 1 && k <= 16 && (10ull << (2 * k)) * 2 > (uint64_t)free_b) k--;  // table + the previous level while building
         uint64_t entries = 1ull << (2 * k);
         uint2 *ta = nullptr, *tb = nullptr;
         HIP_CHECK(hipMalloc((void**)&ta, entries * 8));
@@ -306,13 +312,11 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
         uint2* cur = (k % 2 == 1) ? ta : tb;
         uint2* oth = (k % 2 == 1) ? tb : ta;
         hipLaunchKernelGGL(k_kmer_level1, dim3(1), dim3(64), 0, 0, v, cur);
-        uint32_t prev_entries = 4;
         for (uint32_t lvl = 2; lvl <= k; lvl++) {
-            uint64_t total = (uint64_t)prev_entries * 4;
+            const uint64_t total = 1ull << (2 * lvl);
             hipLaunchKernelGGL(k_kmer_level, dim3((uint32_t)std::min<uint64_t>((total + 255) / 256, 1u << 22)), dim3(256), 0, 0, v, cur, oth,
-                               prev_entries);
+                               2 * (lvl - 1));
             std::swap(cur, oth);
-            prev_entries = (uint32_t)std::min<uint64_t>(total, 0xffffffffull);  // (only read again if another level follows)
         }
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipDeviceSynchronize());

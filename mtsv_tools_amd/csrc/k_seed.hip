@@ -124,9 +124,9 @@ __device__ inline void search_slot(const DevIndexView& ix, const uint8_t* __rest
         int i = (int)K - 1;
         // the seed's last kmer_k symbols in one gather when none of them is N
         if (ix.kmer_tab && K >= ix.kmer_k) {
-            uint32_t idx = 0;
+            uint64_t idx = 0;  // (a table of 17 symbols has 2^34 entries)
             bool acgt = true;
-            if (K <= 21) {
+            if (K <= 21 && ix.kmer_k <= 16) {
                 const uint32_t kk = ix.kmer_k;  // <= 16
                 const uint64_t sub = c_lo >> (3 * (K - kk));  // the last kk symbols, first of them lowest
                 const uint32_t s_lo = (uint32_t)sub & 0x3fffffffu, s_hi = (uint32_t)(sub >> 30) & 0x3ffffu;
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
 // code afterwards, packed into the workgroup's first wavefront(s), so the long walks of a few lanes do not
 // hold every wavefront of the launch.  (A global list fed by one atomic per wavefront made the kernel
 // atomic-bound: ~9 ns per single-address atomic, 2.5 M wavefronts with such a seed on config2.)
+// KK = 17: the 16 packed symbols plus the one in front of them as bits 32-33 of the table index (a table of 2^34 entries).
 template <int KK>
 __global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint8_t* __restrict__ bases,
                                                      const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t total,
@@ -227,16 +228,17 @@ __global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint
             const uint32_t t = (w | (w >> 6)) & 0x000f000fu;
             packed |= ((t | (t >> 12)) & 0xffu) << (8 * k);  // byte i of the 16 at bits [2i, 2i+2)
         }
-        // the KK bytes that count: the last KK of the 16 (forward), the first KK (reverse)
+        // the T bytes that count: the last T of the 16 (forward), the first T (reverse)
+        constexpr int T = KK > 16 ? 16 : KK;
         uint32_t used = 0;  // bit 8q + k set when byte 4k + q is one of them
 #pragma unroll
         for (int i = 0; i < 16; i++) {
-            const bool in = i >= 16 - KK;  // forward strand; mirrored below for the reverse strand
+            const bool in = i >= 16 - T;  // forward strand; mirrored below for the reverse strand
             if (in) used |= 1u << (8 * (i & 3) + (i >> 2));
         }
         uint32_t used_rev = 0;
 #pragma unroll
-        for (int i = 0; i < KK; i++) used_rev |= 1u << (8 * (i & 3) + (i >> 2));
+        for (int i = 0; i < T; i++) used_rev |= 1u << (8 * (i & 3) + (i >> 2));
         slow = (nbits & (strand ? used_rev : used)) != 0;
         if (!slow) {
             uint32_t idx;
@@ -246,19 +248,30 @@ __global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint
                 const uint32_t rv = __builtin_bitreverse32(packed);  // field order reversed, bits inside a field swapped
                 idx = ((rv >> 1) & 0x55555555u) | ((rv & 0x55555555u) << 1);
             }
-            if (KK < 16) idx &= (1u << (2 * KK)) - 1u;
-            const uint2 iv = ix.kmer_tab[idx];
-            lo = iv.x;
-            hi = iv.y;
-            // the K - KK symbols in front of the table part, eight bytes at most
-            const uint32_t fp = strand ? s0 + KK : s0;
+            if (T < 16) idx &= (1u << (2 * T)) - 1u;
+            // the K - T symbols in front of the packed part, eight bytes at most
+            const uint32_t fp = strand ? s0 + T : s0;
             const uint32_t fw = fp >> 2, fsh = fp & 3;
             const uint32_t f0 = b32[fw], f1 = b32[fw + 1], f2 = b32[fw + 2];
             const uint64_t fm = ((uint64_t)__builtin_amdgcn_alignbyte(f2, f1, fsh) << 32) | __builtin_amdgcn_alignbyte(f1, f0, fsh);
-            for (int i = (int)K - KK - 1; i >= 0; i--) {  // wave-uniform trip count
-                // strand-order symbol i: span byte i (forward) or the complement of span byte K-1-i (reverse)
-                uint32_t a = (uint32_t)(fm >> (8 * (strand ? (int)K - 1 - i - KK : i))) & 0xffu;
-                if (strand) a = comp_code(a);
+            // strand-order symbol i: span byte i (forward) or the complement of span byte K-1-i (reverse)
+            auto front = [&](int i) {
+                uint32_t a = (uint32_t)(fm >> (8 * (strand ? (int)K - 1 - i - T : i))) & 0xffu;
+                return strand ? comp_code(a) : a;
+            };
+            int i = (int)K - T - 1;
+            uint64_t tix = idx;
+            if (KK > 16) {  // the table's 17th symbol
+                const uint32_t a = front(i);
+                slow = a > 3;  // N: the general code
+                tix |= (uint64_t)(a & 3u) << 32;
+                i--;
+            }
+            const uint2 iv = ix.kmer_tab[slow ? 0 : tix];
+            lo = iv.x;
+            hi = iv.y;
+            for (; i >= 0; i--) {  // wave-uniform trip count
+                const uint32_t a = front(i);
                 if (lo < hi) {
                     const uint32_t bl = lo >> kBlockShift, bh = hi >> kBlockShift;
                     const LoadedBlock B0 = load_block(ix.blocks, bl);
@@ -579,8 +592,8 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt) {
     uint64_t total = (uint64_t)n_reads * 2 * max_ns;
     if (!total) return;
-    const bool fast = ix.kmer_tab && total < 0xffffffffull && K >= 16 && K <= 24 && ix.kmer_k >= 12 && ix.kmer_k <= 16 &&
-                      K >= ix.kmer_k && K - ix.kmer_k <= 8 && !getenv("MTSV_SEARCH_GENERIC");
+    const bool fast = ix.kmer_tab && total < 0xffffffffull && K >= 16 && K <= 24 && ix.kmer_k >= 12 && ix.kmer_k <= 17 &&
+                      K >= ix.kmer_k && K - std::min<uint32_t>(ix.kmer_k, 16) <= 8 && !getenv("MTSV_SEARCH_GENERIC");
     if (!fast) {
         hipLaunchKernelGGL(k_search, dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, n_reads, max_ns, K, G,
                            seed_lo, seed_cnt);
@@ -594,6 +607,7 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
     case 13: FAST_CASE(13); break;
     case 14: FAST_CASE(14); break;
     case 15: FAST_CASE(15); break;
+    case 17: FAST_CASE(17); break;
     default: FAST_CASE(16); break;
     }
 #undef FAST_CASE

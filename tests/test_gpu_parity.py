@@ -437,7 +437,9 @@ def medium():
     return ix, bases, off
 
 
-@pytest.mark.parametrize("k,extra", [("16", {}), ("15", {}), ("14", {}), ("13", {}), ("12", {}), ("11", {}),
+@pytest.mark.parametrize("k,extra", [("17", {}), ("17", dict(seed_size=17, seed_interval=9)), ("17", dict(seed_size=25)),
+                                     ("17", dict(seed_size=16, seed_interval=7)),
+                                     ("16", {}), ("15", {}), ("14", {}), ("13", {}), ("12", {}), ("11", {}),
                                      ("16", dict(seed_size=24, seed_interval=11)), ("12", dict(seed_size=20)),
                                      ("16", dict(seed_size=16, seed_interval=7)), ("13", dict(seed_size=22))])
 def test_kmer_table_width_does_not_change_hits(tricky, monkeypatch, k, extra):
