@@ -1069,8 +1069,11 @@ __device__ inline int row_suffix_incl16(int v) {
 constexpr uint32_t kDiagBuf = 128;  // decisions a wavefront of k_sw_diag buffers per list
 
 // NW: words of four read positions per lane (16 * 4 * NW >= the longest read of the pass)
+#ifndef MTSV_DIAG_OCC
+#define MTSV_DIAG_OCC 6
+#endif
 template <int NW>
-__global__ __launch_bounds__(256) void k_sw_diag(DevIndexView ix, EvalArgs a, uint32_t* __restrict__ sweep_list, uint32_t sweep_slot) {
+__global__ __launch_bounds__(256, MTSV_DIAG_OCC) void k_sw_diag(DevIndexView ix, EvalArgs a, uint32_t* __restrict__ sweep_list, uint32_t sweep_slot) {
     __shared__ uint32_t buf_all[256 / kWave][2][kDiagBuf];
     uint32_t* pbuf = buf_all[threadIdx.x / kWave][0];
     uint32_t* sbuf = buf_all[threadIdx.x / kWave][1];
