@@ -828,7 +828,9 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
         }
         if (__all(phase == PH_DONE)) break;
         bool finish = false;
-        if (phase == PH_SWEEP) {
+        // A sweeping group stays in this loop until its pair is decided (groups that are done wait at its end for
+        // their siblings, as they would in the outer loop, which has nothing for a sweeping group to do between trips).
+        if (phase == PH_SWEEP) do {
             uint8_t* rings = &ring_all[threadIdx.x / GS][0][0];
             // windows longer than the ring: see k_evaluate
 #pragma unroll
@@ -956,7 +958,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                 }
                 finish = t >= steps;
             }
-        }
+        } while (!finish);
         if (__builtin_expect(phase == PH_SWEEP && finish, 0)) {
             int bm[2];
             swept += t;
