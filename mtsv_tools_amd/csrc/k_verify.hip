@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
     // group-uniform flags kept as bits of one VGPR (as separate bools they live in SGPR pairs, and this
     // kernel is already at the SGPR limit): bit hf = chain pending, 2 + hf = hopeless read, 4 = worklist drained
     uint32_t gf = 0;
-    constexpr uint32_t F_CHAIN = 1u, F_HOPELESS = 4u, F_DRAINED = 16u;
+    constexpr uint32_t F_CHAIN = 1u, F_HOPELESS = 4u, F_DRAINED = 16u, F_LONG = 32u;  // F_LONG: a window of this pair exceeds the ring
     uint32_t qc2[R];  // read codes << 1, both halves
     uint32_t h[R], up_prev = 0, best = 0;
     uint32_t bot = 0;  // TOP: largest H of the lane's last row over the swept columns (lane 15: the bottom covered row)
@@ -806,6 +806,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                 bot = 0;
                 t = 0;
                 steps = max(Wn[0], Wn[1]) + GS - 1;
+                gf = max(Wn[0], Wn[1]) > kRingP ? (gf | F_LONG) : (gf & ~F_LONG);
                 // Decision points: the first where a window without a real alignment typically runs out of
                 // columns (Wn - thr columns swept, plus the lane skew and the score such a window reaches
                 // by chance), the second where a true alignment typically reaches the threshold (its
@@ -835,6 +836,7 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
             // windows longer than the ring: see k_evaluate
 #pragma unroll
             for (int hf = 0; hf < 2; hf++) {
+                if (__builtin_expect((gf & F_LONG) != 0, 0))
                 if (Wn[hf] > kRingP && t >= kRingP / 2 + GS && ((t - GS) & (kRingP / 2 - 1)) == 0) {
                     const uint32_t from = (t - GS) + kRingP / 2, to = min(Wn[hf], from + kRingP / 2);
                     const uint32_t wstart = a.cand[g[hf]].x;  // long windows only: not worth a register
@@ -914,6 +916,9 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                 // four columns per trip: this lane's columns j0 .. j0+3 of both windows come from the rings as two
                 // aligned dwords + v_alignbyte each; columns outside [0, Wn) read as 7 (matches nothing)
                 const int j0 = (int)t - (int)gl;
+                // every lane's four columns inside both windows (a half that is not sweeping has Wn = 0 and is ignored):
+                // most trips of a sweep, and then no edge masks are needed
+                const bool interior = t >= (uint32_t)(GS - 1) && min(Wn[0] - 1u, Wn[1] - 1u) >= t + 3u;
                 uint32_t four2[2];
 #pragma unroll
                 for (int hf = 0; hf < 2; hf++) {
@@ -921,6 +926,10 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexV
                     const int w = j0 >> 2;  // arithmetic: floor for the negative columns of the pipeline fill
                     const uint32_t d0 = ring32[(uint32_t)w & (kRingP / 4 - 1)], d1 = ring32[(uint32_t)(w + 1) & (kRingP / 4 - 1)];
                     const uint32_t four = __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)j0 & 3u);
+                    if (interior) {
+                        four2[hf] = four << 1;
+                        continue;
+                    }
                     const int lo = min(max(-j0, 0), 4), hi = min(max((int)Wn[hf] - j0, 0), 4);  // valid bytes: [lo, hi)
                     const uint32_t mlo = lo >= 4 ? 0xffffffffu : (1u << (8 * lo)) - 1u;
                     const uint32_t mhi = hi >= 4 ? 0xffffffffu : (1u << (8 * hi)) - 1u;
