@@ -427,7 +427,7 @@ def main():
                         hbm["k_search"] = {"bound": "hbm", "ms": stage_ms["search"], "traffic": sb, "achieved": sb / (stage_ms["search"] * 1e-3) / 1e9,
                                            "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sb / (stage_ms["search"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                            "note": "measured FETCH_SIZE + WRITE_SIZE of k_search (raw counters of the profiled run, see measured_traffic_source) over its "
-                                                   "HIP-event time in this run; ~5 dependent 64-byte gathers per seed"}
+                                                   "HIP-event time in this run; per seed one 8-byte gather in the k-mer table and two 64-byte rank blocks per FM step left"}
             except Exception:
                 pass
         roof["hbm"] = hbm
