@@ -605,6 +605,29 @@ def test_prefilter_stages_decide_alike(medium, tricky, monkeypatch):
                 assert 0 < st["sw_cell_pairs"]
 
 
+@pytest.mark.parametrize("edit_rate", [0.0, 0.04, 0.2, 0.3, 0.45])
+def test_prefilter_kernels_at_other_tolerances(tricky, edit_rate):
+    """The threshold L - 2*ED moves the geometry of every bound: at 0.3 an alignment below the top half of the rows
+    alone can reach it (those candidates skip the top-half sweep), at 0.45 and above nearly every read is refuted
+    late or wraps (2*ED > L), at 0 the window is the read's length and only an exact copy passes."""
+    ix, orc, reads = tricky
+    reads = [r for r in reads if len(r) <= 253]
+    bases, off = helpers.reads_to_batch(reads)
+    mp, op = both_params(edit_rate=edit_rate)
+    ix.to_device(0)
+    want, ctr = orc.bin_batch(bases, off, op, threads=8)
+    b = M.Batch(ix, 0, len(reads), len(bases))
+    b.upload(bases, off)
+    for mode in (0, 1):
+        b.set_verify_mode(mode)
+        b.run(mp)
+        assert_same_hits(b.download(), want)
+        st = b.stats()
+        if mode == 0:
+            assert (st["n_verified"], st["window_bytes"]) == (ctr["n_sw"], ctr["W"])
+    b.close()
+
+
 def test_page_locked_input_is_read_in_place(medium, capfd, monkeypatch):
     """bases in memory from mtsv_host_alloc, or registered with mtsv_host_register, skip the staging copy of
     run_host (MTSV_TRACE names the route); the hits do not depend on where the bases lie"""
