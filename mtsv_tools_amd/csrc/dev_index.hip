@@ -306,8 +306,19 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
         while (k > 1 && k <= 16 && (10ull << (2 * k)) * 2 > (uint64_t)free_b) k--;  // table + the previous level while building
         uint64_t entries = 1ull << (2 * k);
         uint2 *ta = nullptr, *tb = nullptr;
-        HIP_CHECK(hipMalloc((void**)&ta, entries * 8));
-        HIP_CHECK(hipMalloc((void**)&tb, std::max<uint64_t>(entries / 4, 4) * 8));
+        if (k == 17) {  // 128 + 32 GiB in two pieces: free memory by the count is not always free memory in one piece
+            if (hipMalloc((void**)&ta, entries * 8) != hipSuccess || hipMalloc((void**)&tb, entries / 4 * 8) != hipSuccess) {
+                (void)hipGetLastError();
+                if (ta) (void)hipFree(ta);
+                ta = tb = nullptr;
+                k = 16;
+                entries = 1ull << 32;
+            }
+        }
+        if (!ta) {
+            HIP_CHECK(hipMalloc((void**)&ta, entries * 8));
+            HIP_CHECK(hipMalloc((void**)&tb, std::max<uint64_t>(entries / 4, 4) * 8));
+        }
         // ping-pong so the last level lands in `ta`
         uint2* cur = (k % 2 == 1) ? ta : tb;
         uint2* oth = (k % 2 == 1) ? tb : ta;
