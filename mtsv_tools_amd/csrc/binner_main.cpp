@@ -16,6 +16,7 @@
 //                     collapse.rs:597-625: smallest edit per read and TaxId)
 #include <zlib.h>
 
+#include <atomic>
 #include <cerrno>
 #include <condition_variable>
 #include <deque>
@@ -637,6 +638,60 @@ int main(int argc, char** argv) {
         parsed.close();
     });
 
+    // helper threads of the result side: the formatting of a batch's hits runs on them in parallel, and the
+    // finished text of batch k is written (positional writes at offsets fixed in batch order) while batch k+1
+    // is being formatted
+    struct Helpers {
+        std::mutex mu;
+        std::condition_variable cv, idle;
+        std::deque<std::function<void()>> q;
+        std::vector<std::thread> th;
+        size_t running = 0;
+        bool stop = false;
+        explicit Helpers(unsigned n) {
+            for (unsigned i = 0; i < n; i++)
+                th.emplace_back([this] {
+                    for (;;) {
+                        std::function<void()> f;
+                        {
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return stop || !q.empty(); });
+                            if (q.empty()) return;
+                            f = std::move(q.front());
+                            q.pop_front();
+                            running++;
+                        }
+                        f();
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            running--;
+                        }
+                        idle.notify_all();
+                    }
+                });
+        }
+        void submit(std::function<void()> f) {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                q.push_back(std::move(f));
+            }
+            cv.notify_one();
+        }
+        void wait_all() {
+            std::unique_lock<std::mutex> lk(mu);
+            idle.wait(lk, [&] { return q.empty() && running == 0; });
+        }
+        ~Helpers() {
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                stop = true;
+            }
+            cv.notify_all();
+            for (auto& t : th) t.join();
+        }
+    };
+    Helpers fmt_pool(host_threads), write_pool(std::max(2u, host_threads / 2));
+    std::atomic<bool> write_failed{false};
     std::thread writer([&] {
         uint64_t total = 0, next_seq = 0;
         std::vector<std::unique_ptr<Work>> held;  // batches that finished ahead of their turn
@@ -677,11 +732,12 @@ int main(int argc, char** argv) {
                                             long_fmt, &text[k], &len[k]);
                 if (rc[k] != MTSV_OK) msg[k] = mtsv_last_error();  // thread-local
             };
-            {
-                std::vector<std::thread> th;
-                for (unsigned k = 1; k < parts; k++) th.emplace_back(fmt, k);
+            if (parts > 1) {
+                for (unsigned k = 1; k < parts; k++) fmt_pool.submit([&fmt, k] { fmt(k); });
                 fmt(0);
-                for (auto& t : th) t.join();
+                fmt_pool.wait_all();
+            } else {
+                fmt(0);
             }
             mtsv_hits_free(w->hits);
             bool ok = true;
@@ -691,40 +747,37 @@ int main(int argc, char** argv) {
                     set_code(2);
                     ok = false;
                 }
-            if (ok && !failed()) {
-                std::vector<off_t> at(parts);
+            if (ok && !failed() && !write_failed.load()) {
                 for (unsigned k = 0; k < parts; k++) {
-                    at[k] = out_pos;
+                    const off_t at = out_pos;
                     out_pos += (off_t)len[k];
-                }
-                std::vector<char> bad(parts, 0);
-                auto put = [&](unsigned k) {
-                    uint64_t done = 0;
-                    while (done < len[k]) {
-                        ssize_t r = pwrite(out_fd, text[k] + done, len[k] - done, at[k] + (off_t)done);
-                        if (r <= 0) {
-                            bad[k] = 1;
-                            return;
+                    char* tx = text[k];
+                    const uint64_t ln = len[k];
+                    text[k] = nullptr;  // the write job owns it now
+                    write_pool.submit([tx, ln, at, out_fd, &write_failed] {
+                        uint64_t done = 0;
+                        while (done < ln) {
+                            ssize_t r = pwrite(out_fd, tx + done, ln - done, at + (off_t)done);
+                            if (r <= 0) {
+                                write_failed.store(true);
+                                break;
+                            }
+                            done += (uint64_t)r;
                         }
-                        done += (uint64_t)r;
-                    }
-                };
-                std::vector<std::thread> th;
-                for (unsigned k = 1; k < parts; k++) th.emplace_back(put, k);
-                put(0);
-                for (auto& t : th) t.join();
-                for (unsigned k = 0; k < parts; k++)
-                    if (bad[k] && ok) {
-                        logmsg("ERROR", "Error writing to result file");
-                        set_code(11);  // binner.rs:136-139
-                        ok = false;
-                    }
+                        mtsv_free(tx);
+                    });
+                }
             }
             for (unsigned k = 0; k < parts; k++) mtsv_free(text[k]);
             pool.put(std::move(w->rb));
             if (!ok) continue;
             total += n_reads;
             logmsg("DEBUG", "taxonomic binning: " + std::to_string(total) + " reads done");
+        }
+        write_pool.wait_all();
+        if (write_failed.load()) {
+            logmsg("ERROR", "Error writing to result file");
+            set_code(11);  // binner.rs:136-139
         }
     });
 
