@@ -2,7 +2,7 @@
 """The SW predicate of index.rs:406 on a benchmark workload, in aggregate: the number of candidates the prefilter
 kernels pass on (stats n_sw_passed) against the number of edit distances the oracle computes (n_edit), with the
 first-round bounds as a kernel of their own (k_sw_diag) and inside k_sw_pairs, on reads that are not settled by
-their N count.  Usage: tools/check_sw_passed.py [config1|config2] [n_reads]"""
+their N count.  Usage: tests/check_sw_passed.py [config1|config2] [n_reads]"""
 import math
 import os
 import sys

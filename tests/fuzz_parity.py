@@ -1,6 +1,6 @@
 """Randomised parity soak: random small databases, reads of random lengths / damage, random parameters;
 the HIP path (both evaluation orders, through the C ABI) against the CPU oracle, every field of every hit
-and the work counters.  FUZZ_BIG=1 makes the batches large enough to run as concurrent lanes.  `python tools/fuzz_parity.py [iterations] [seed]`  (needs a GPU; ~1 s per iteration)."""
+and the work counters.  FUZZ_BIG=1 makes the batches large enough to run as concurrent lanes.  `python tests/fuzz_parity.py [iterations] [seed]`  (needs a GPU; ~1 s per iteration)."""
 import os
 import random
 import sys

@@ -728,11 +728,11 @@ def test_gpu_index_builder_writes_the_same_bytes(tmp_path):
 
 
 def test_randomised_soak_short(tmp_path):
-    """25 iterations of tools/fuzz_parity.py (random databases, read lengths 1..400, damage, parameters,
+    """25 iterations of tests/fuzz_parity.py (random databases, read lengths 1..400, damage, parameters,
     device-structure flags; both evaluation orders against the oracle).  800 iterations over three seeds
     were run clean when this was committed."""
     import importlib.util
-    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "..", "tools", "fuzz_parity.py"))
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(os.path.dirname(__file__), "fuzz_parity.py"))
     fz = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(fz)
     for it in range(25):
