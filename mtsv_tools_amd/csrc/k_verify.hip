@@ -451,6 +451,7 @@ __device__ inline int row_max16(int v) {
 #define MTSV_SW_OCC 3
 #endif
 constexpr int kSwOcc = MTSV_SW_OCC;  // resident workgroups of k_sw_pairs per CU
+constexpr int kSwTopOcc = 4;         // ... of its top-half instantiations (half the rows: 4 x 40 KiB of LDS fill the CU; 10.2 -> 10.0 ms)
 constexpr uint32_t kRingP = 512;  // window bytes resident per candidate in k_sw_pairs
 #ifndef MTSV_SW_DECIDE
 #define MTSV_SW_DECIDE 8
@@ -492,7 +493,7 @@ __device__ inline uint32_t* sw_pass_count(const EvalArgs& a) { return reinterpre
 // und_list (flagged like k_sw_diag's output) for the full-height launch.  Reads that fit the rows are decided
 // exactly as without TOP.
 template <int R, bool DIAG, bool TOP = false>
-__global__ __launch_bounds__(256, R > 10 ? 3 : kSwOcc) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
+__global__ __launch_bounds__(256, R > 10 ? 3 : (TOP ? kSwTopOcc : kSwOcc)) void k_sw_pairs(DevIndexView ix, EvalArgs a) {
     static_assert(!(TOP && DIAG), "the bounds on the seed diagonal need the whole read");
     constexpr int GS = 16;
     __shared__ __attribute__((aligned(16))) uint8_t ring_all[256 / GS][2][kRingP];
@@ -1589,7 +1590,7 @@ void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, 
     if (top) {  // the top half of the rows (a.und_list / a.und_slot take what they cannot decide)
 #define SW_TOP(RR)                                                                                                       \
     do {                                                                                                                 \
-        const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * kSwOcc));              \
+        const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 32), 256 * kSwTopOcc));           \
         a.claim_shift = 0;                                                                                               \
         while ((1ull << a.claim_shift) < (uint64_t)grid * 16 * 2) a.claim_shift++;                                       \
         hipLaunchKernelGGL((k_sw_pairs<RR, false, true>), dim3(grid), dim3(256), 0, s, ix, a);                           \
