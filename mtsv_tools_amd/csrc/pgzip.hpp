@@ -132,9 +132,119 @@ static const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 
 static const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
 static const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
 
+// Two-level decoding table for the literal/length and distance codes: a root of ROOT bits (codes up to that length
+// decode with one look-up in a table that stays in the L1 cache) and sub-tables for the longer ones.  An entry says
+// everything the inner loop needs: bits 0-4 the code's length, bits 5-7 its kind, bits 8-11 the extra bits of a
+// length / distance (or the index width of a sub-table), bits 16-31 the literal, the base value, or the sub-table's
+// offset.  Building one costs ~1 K entries, not 2^15 as a flat table of the longest code would.
+struct FastHuff {
+    enum : uint32_t { INVALID = 0, LITERAL = 1, BASE = 2, END = 3, SUB = 4 };
+    static constexpr int kMaxEntries = 1024 + 2048;
+    uint32_t tab[kMaxEntries];
+    int root = 0;
+    static uint32_t make(uint32_t len, uint32_t kind, uint32_t extra, uint32_t value) { return len | (kind << 5) | (extra << 8) | (value << 16); }
+    static uint32_t len_of(uint32_t e) { return e & 31u; }
+    static uint32_t kind_of(uint32_t e) { return (e >> 5) & 7u; }
+    static uint32_t extra_of(uint32_t e) { return (e >> 8) & 15u; }
+    static uint32_t value_of(uint32_t e) { return e >> 16; }
+    // lit_len: symbols 0..255 literals, 256 end of block, 257..285 lengths; else distance symbols 0..29
+    bool build(const uint8_t* len, int n, bool allow_single, int root_bits, bool lit_len) {
+        int count[16] = {0};
+        for (int i = 0; i < n; i++) count[len[i]]++;
+        count[0] = 0;
+        int maxl = 15;
+        while (maxl > 0 && count[maxl] == 0) maxl--;
+        root = root_bits;
+        if (maxl == 0) {
+            for (int i = 0; i < (1 << root); i++) tab[i] = 0;
+            return allow_single;  // no codes at all: legal only for an unused distance tree
+        }
+        long left = 1;
+        for (int l = 1; l <= maxl; l++) {
+            left = (left << 1) - count[l];
+            if (left < 0) return false;
+        }
+        int used = 0;
+        for (int l = 1; l <= 15; l++) used += count[l];
+        if (left > 0 && !(allow_single && used == 1 && maxl == 1)) return false;  // zlib: an incomplete set only as one 1-bit distance code
+        if (root > maxl) root = maxl;
+        const uint32_t root_size = 1u << root;
+        for (uint32_t i = 0; i < root_size; i++) tab[i] = 0;
+        int next[16], code = 0;
+        for (int l = 1; l <= maxl; l++) {
+            code = (code + count[l - 1]) << 1;
+            next[l] = code;
+        }
+        // first pass over the long codes: the longest code under every root prefix gives its sub-table's width
+        uint8_t sub_bits[1 << 11] = {0};  // root <= 11
+        uint32_t rev_of[288];
+        for (int sy = 0; sy < n; sy++) {
+            const int l = len[sy];
+            if (!l) continue;
+            const uint32_t c = (uint32_t)next[l]++;
+            uint32_t r = 0;
+            for (int b = 0; b < l; b++) r |= ((c >> b) & 1u) << (l - 1 - b);  // codes are sent MSB first
+            rev_of[sy] = r;
+            if (l > root) {
+                const uint32_t pre = r & (root_size - 1);
+                if ((int)sub_bits[pre] < l - root) sub_bits[pre] = (uint8_t)(l - root);
+            }
+        }
+        uint32_t used_entries = root_size;
+        if (maxl > root)
+            for (uint32_t pre = 0; pre < root_size; pre++)
+                if (sub_bits[pre]) {
+                    if (used_entries + (1u << sub_bits[pre]) > (uint32_t)kMaxEntries) return false;
+                    tab[pre] = make((uint32_t)root, SUB, sub_bits[pre], used_entries);
+                    for (uint32_t i = 0; i < (1u << sub_bits[pre]); i++) tab[used_entries + i] = 0;
+                    used_entries += 1u << sub_bits[pre];
+                }
+        for (int sy = 0; sy < n; sy++) {
+            const int l = len[sy];
+            if (!l) continue;
+            uint32_t e;
+            if (lit_len) {
+                if (sy < 256) e = make((uint32_t)l, LITERAL, 0, (uint32_t)sy);
+                else if (sy == 256) e = make((uint32_t)l, END, 0, 0);
+                else if (sy <= 285) e = make((uint32_t)l, BASE, kLenExtra[sy - 257], kLenBase[sy - 257]);
+                else e = 0;  // 286, 287: in the fixed code's alphabet, never valid
+            } else {
+                e = sy <= 29 ? make((uint32_t)l, BASE, kDistExtra[sy], kDistBase[sy]) : 0;
+            }
+            const uint32_t r = rev_of[sy];
+            if (l <= root) {
+                for (uint32_t i = r; i < root_size; i += 1u << l) tab[i] = e;
+            } else {
+                const uint32_t pre = r & (root_size - 1), sb = sub_bits[pre], ofs = value_of(tab[pre]);
+                for (uint32_t i = r >> root; i < (1u << sb); i += 1u << (l - root)) tab[ofs + i] = e;
+            }
+        }
+        return true;
+    }
+};
+
+// a vector that does not fill what resize() adds: the inflater writes through raw pointers into room it has resized
+// into, and resizes back to what it wrote
+template <class T>
+struct NoInit : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = NoInit<U>;
+    };
+    template <class U>
+    void construct(U* p) {
+        ::new ((void*)p) U;
+    }
+    template <class U, class A0, class... A>
+    void construct(U* p, A0&& a0, A&&... a) {
+        ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...);
+    }
+};
+using SymVec = std::vector<uint16_t, NoInit<uint16_t>>;
+
 // output of one chunk: symbols < 256 are bytes, 256 + i = byte i of the window before the chunk
 struct Symbols {
-    std::vector<uint16_t> s;
+    SymVec s;
     uint64_t member_start = 0;  // symbols before this index belong to an earlier gzip member
     uint64_t marker_end = 0;    // no symbol at or after this index is a window reference
 };
@@ -153,7 +263,8 @@ struct Inflater {
     bool text_only;  // entry-point validation: stop with an error at the first byte that is not text
     uint64_t stop_symbols = ~0ull;  // validation: leave a block once this many symbols are out
     std::string err;
-    Huff lit, dist;
+    FastHuff lit, dist;
+    static constexpr int kLitRoot = 10, kDistRoot = 8;
     Inflater(const uint8_t* b, const uint8_t* e, uint64_t bitpos, Symbols* o, std::vector<Member>* m, bool text)
         : br(b, e, bitpos), out(o), members(m), text_only(text) {}
 
@@ -197,8 +308,8 @@ struct Inflater {
             }
         }
         if (lens[256] == 0) return fail("no end-of-block code");
-        if (!lit.build(lens, (int)hlit, false)) return fail("bad literal/length code");
-        if (!dist.build(lens + hlit, (int)hdist, true)) return fail("bad distance code");
+        if (!lit.build(lens, (int)hlit, false, kLitRoot, true)) return fail("bad literal/length code");
+        if (!dist.build(lens + hlit, (int)hdist, true, kDistRoot, false)) return fail("bad distance code");
         return !br.overrun_now();
     }
     void set_fixed() {
@@ -207,81 +318,112 @@ struct Inflater {
         for (int i = 144; i < 256; i++) l[i] = 9;
         for (int i = 256; i < 280; i++) l[i] = 7;
         for (int i = 280; i < 288; i++) l[i] = 8;
-        lit.build(l, 288, false);
+        lit.build(l, 288, false, kLitRoot, true);
         uint8_t d[32];
         for (int i = 0; i < 32; i++) d[i] = 5;
-        dist.build(d, 32, true);  // 32 five-bit codes; 30 and 31 never occur in valid data (checked where they are decoded)
+        dist.build(d, 32, true, kDistRoot, false);  // 32 five-bit codes; 30 and 31 never occur in valid data (their entries are invalid)
     }
+    // While a block body runs, out->s.size() is the ROOM (resized into without initialisation) and n_ the count; the
+    // body leaves with size() == count again.
+    uint64_t n_ = 0;
+    void open_room(uint64_t want) {
+        if (out->s.size() < n_ + want) out->s.resize(std::max<uint64_t>(n_ + want, out->s.size() + out->s.size() / 2 + (1 << 16)));
+    }
+    uint32_t decode(const FastHuff& h) {
+        uint32_t e = h.tab[(uint32_t)br.buf & ((1u << h.root) - 1u)];
+        if (FastHuff::kind_of(e) == FastHuff::SUB)
+            e = h.tab[FastHuff::value_of(e) + ((uint32_t)(br.buf >> h.root) & ((1u << FastHuff::extra_of(e)) - 1u))];
+        br.consume((int)FastHuff::len_of(e));  // (an invalid entry has length 0)
+        return e;
+    }
+    template <bool VALIDATE>
     bool copy(uint32_t len, uint32_t d) {
-        std::vector<uint16_t>& s = out->s;
-        const uint64_t have = s.size() - out->member_start;  // symbols of the current member inside this chunk
+        const uint64_t have = n_ - out->member_start;  // symbols of the current member inside this chunk
         if (d > kWindow) return fail("distance beyond the window");
         if (d > have) {
             // reaches before the chunk: only legal while the current member started before the chunk
             if (out->member_start != 0) return fail("reference before the start of its member");
         }
-        const uint64_t n0 = s.size();
-        s.resize(n0 + len);
-        uint16_t* o = s.data() + n0;
+        uint16_t* s0 = out->s.data();
+        const uint64_t n0 = n_;
+        uint16_t* o = s0 + n0;
         if (d <= n0) {
             const uint16_t* src = o - d;
             const bool may_mark = n0 - d < out->marker_end;  // the source range can hold window references
-            for (uint32_t j = 0; j < len; j++) o[j] = src[j];  // (overlapping on purpose: d < len repeats)
+            if (d >= 8) {  // eight symbols at a time; the room reaches 320 symbols past the count (overlap: d < len repeats)
+                for (uint32_t j = 0; j < len; j += 8) memcpy(o + j, src + j, 16);
+            } else {
+                for (uint32_t j = 0; j < len; j++) o[j] = src[j];
+            }
             if (may_mark) {
                 for (uint32_t j = 0; j < len; j++)
                     if (o[j] >= 256) out->marker_end = n0 + j + 1;
             }
-            if (text_only)
+            if (VALIDATE && text_only)
                 for (uint32_t j = 0; j < len; j++)
                     if (o[j] < 256 && !is_text(o[j])) return fail("binary data");
+            n_ = n0 + len;
             return true;
         }
         for (uint32_t j = 0; j < len; j++) {
             const uint64_t n = n0 + j;
             uint16_t v;
             if (d <= n) {
-                v = s[n - d];
+                v = s0[n - d];
             } else {
                 const uint64_t back = d - n;  // bytes before the chunk: window index kWindow - back
                 v = (uint16_t)(256 + (kWindow - back));
             }
             if (v >= 256) out->marker_end = n + 1;
-            if (text_only && v < 256 && !is_text(v)) return fail("binary data");
+            if (VALIDATE && text_only && v < 256 && !is_text(v)) return fail("binary data");
             o[j] = v;
         }
+        n_ = n0 + len;
         return true;
     }
-    bool inflate_block_body() {
+    // VALIDATE: entry-point validation (text only, leave after stop_symbols)
+    template <bool VALIDATE>
+    bool block_body() {
+        n_ = out->s.size();
+        struct Close {
+            Inflater* f;
+            ~Close() { f->out->s.resize(f->n_); }
+        } close{this};
+        open_room(1 << 16);
         for (;;) {
             // past the end of the input the reader supplies zero bits: a code set in which those decode to a literal
             // would otherwise never stop (entry-point validation runs on arbitrary bit positions)
             if (br.p > br.end + 8) return fail("truncated");
-            if (out->s.size() >= stop_symbols) return true;  // validation: enough seen (run() stops at its limit next)
-            br.refill();
-            const uint16_t e = lit.tab[br.peek(lit.bits)];
-            if (!e) return fail("bad literal/length symbol");
-            br.consume(e & 15);
-            const uint32_t sym = e >> 4;
-            if (sym < 256) {
-                if (text_only && !is_text(sym)) return fail("binary data");
-                out->s.push_back((uint16_t)sym);
-            } else if (sym == 256) {
-                return !br.overrun_now() || fail("truncated");
-            } else {
-                if (sym > 285) return fail("bad length symbol");
-                const uint32_t len = kLenBase[sym - 257] + br.get(kLenExtra[sym - 257]);
-                br.refill();
-                const uint16_t de = dist.tab[br.peek(dist.bits)];
-                if (!de) return fail("bad distance symbol");
-                br.consume(de & 15);
-                const uint32_t ds = de >> 4;
-                if (ds > 29) return fail("bad distance symbol");
-                const uint32_t d = kDistBase[ds] + br.get(kDistExtra[ds]);
-                if (!copy(len, d)) return false;
+            if (VALIDATE && n_ >= stop_symbols) return true;  // validation: enough seen (run() stops at its limit next)
+            if (out->s.size() < n_ + 320) open_room(1 << 16);
+            uint16_t* o = out->s.data();
+            br.refill();  // 56 bits or more: a symbol takes at most 15, a length 5 more; the distance refills again
+            uint32_t e = decode(lit);
+            bool again = false;
+            while (FastHuff::kind_of(e) == FastHuff::LITERAL) {
+                const uint32_t c = FastHuff::value_of(e);
+                if (VALIDATE && text_only && !is_text(c)) return fail("binary data");
+                o[n_++] = (uint16_t)c;
+                if (br.cnt < 20) {  // fewer than a symbol and a length's extra bits left: back to the refill
+                    again = true;
+                    break;
+                }
+                e = decode(lit);
             }
-            if (br.overrun_now()) return fail("truncated");
+            if (again) continue;
+            const uint32_t k = FastHuff::kind_of(e);
+            if (k == FastHuff::END) return !br.overrun_now() || fail("truncated");
+            if (k != FastHuff::BASE) return fail("bad literal/length symbol");
+            const uint32_t len = FastHuff::value_of(e) + br.get((int)FastHuff::extra_of(e));
+            br.refill();
+            const uint32_t de = decode(dist);
+            if (FastHuff::kind_of(de) != FastHuff::BASE) return fail("bad distance symbol");
+            const uint32_t d = FastHuff::value_of(de) + br.get((int)FastHuff::extra_of(de));
+            if (!copy<VALIDATE>(len, d)) return false;
+            if (VALIDATE && br.overrun_now()) return fail("truncated");
         }
     }
+    bool inflate_block_body() { return (text_only || stop_symbols != ~0ull) ? block_body<true>() : block_body<false>(); }
     // gzip member header at the (byte-aligned) reader position; false on anything unexpected
     bool skip_member_header() {
         br.align_byte();
