@@ -683,17 +683,29 @@ class ParallelGunzip {
                     o.resize(n);
                     const uint16_t* sy = c.sym.s.data();
                     const uint64_t me = std::min<uint64_t>(c.sym.marker_end, n);
-                    for (uint64_t j = 0; j < me; j++) {
-                        uint16_t v = sy[j];
-                        if (v >= 256) {
-                            const uint64_t idx = v - 256;
-                            if (idx + pw.size() < kWindow) {
-                                errs[k] = "reference before the start of the stream";
-                                return;
+                    if (pw.size() == kWindow && me > 4096) {
+                        // a full window before the chunk (every chunk but the stream's first): one table maps bytes to
+                        // themselves and window references to the window's bytes -- no branch per symbol (in FASTQ the
+                        // references live on through most of a chunk)
+                        std::vector<uint8_t> lut(256 + kWindow);
+                        for (uint32_t v = 0; v < 256; v++) lut[v] = (uint8_t)v;
+                        memcpy(lut.data() + 256, pw.data(), kWindow);
+                        uint8_t* od = o.data();
+                        const uint8_t* lt = lut.data();
+                        for (uint64_t j = 0; j < me; j++) od[j] = lt[sy[j]];
+                    } else {
+                        for (uint64_t j = 0; j < me; j++) {
+                            uint16_t v = sy[j];
+                            if (v >= 256) {
+                                const uint64_t idx = v - 256;
+                                if (idx + pw.size() < kWindow) {
+                                    errs[k] = "reference before the start of the stream";
+                                    return;
+                                }
+                                v = pw[idx - (kWindow - pw.size())];
                             }
-                            v = pw[idx - (kWindow - pw.size())];
+                            o[j] = (uint8_t)v;
                         }
-                        o[j] = (uint8_t)v;
                     }
                     uint8_t* ob = o.data();
                     for (uint64_t j = me; j < n; j++) ob[j] = (uint8_t)sy[j];  // plain narrowing: vectorises
