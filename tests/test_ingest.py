@@ -184,6 +184,35 @@ def test_gzip_input_parallel_inflate_equals_the_serial_stream(tmp_path):
     assert parse_gz(tmp_path / "a.fa.gz", False, chunk=65536, block=30000) == parse_only(tmp_path / "a.fa", False, serial=True)
 
 
+def test_gzip_block_types_and_code_shapes(tmp_path):
+    """every deflate block type behind an entry point of the parallel inflater, and code sets of other shapes than
+    gzip -6 makes: members compressed with Z_FIXED (fixed Huffman blocks), Z_HUFFMAN_ONLY (no matches, one unused
+    distance tree), Z_RLE (distance 1 only: a single distance code), level 0 (stored), window bits 9 (short
+    distances) -- between ordinary members, so that chunks start in one kind and run into the next"""
+    import zlib
+    rng = random.Random(12)
+    text = fastq_text(rng, 24000, at_quality=False).encode()
+    want_path = tmp_path / "s.fq"
+    want_path.write_bytes(text)
+    want = parse_only(want_path, True, serial=True)
+    assert want[0] == 0
+    cuts = [0]
+    for k in range(1, 12):  # cut between records
+        cuts.append(text.index(b"\n@r", len(text) * k // 12) + 1)
+    cuts.append(len(text))
+    shapes = [(6, zlib.Z_DEFAULT_STRATEGY, 15), (6, zlib.Z_FIXED, 15), (6, zlib.Z_DEFAULT_STRATEGY, 15), (6, zlib.Z_HUFFMAN_ONLY, 15),
+              (9, zlib.Z_DEFAULT_STRATEGY, 15), (6, zlib.Z_RLE, 15), (1, zlib.Z_DEFAULT_STRATEGY, 15), (0, zlib.Z_DEFAULT_STRATEGY, 15),
+              (6, zlib.Z_DEFAULT_STRATEGY, 9), (6, zlib.Z_FILTERED, 15), (6, zlib.Z_FIXED, 9), (6, zlib.Z_DEFAULT_STRATEGY, 15)]
+    p = tmp_path / "s.fq.gz"
+    with open(p, "wb") as f:
+        for (level, strategy, wbits), a, b in zip(shapes, cuts, cuts[1:]):
+            c = zlib.compressobj(level, zlib.DEFLATED, 16 + wbits, 9, strategy)
+            f.write(c.compress(text[a:b]) + c.flush())
+    assert parse_gz(p, True, serial=True) == want
+    for chunk, threads in ((None, 4), (65536, 6), (150000, 3), (400000, 2)):
+        assert parse_gz(p, True, chunk=chunk, threads=threads) == want, (chunk, threads)
+
+
 def test_gzip_input_irregular_and_corrupt_files(tmp_path):
     """wrapped FASTQ inside a .gz falls back to the serial reader from the offset of the first block the strict
     parse rejects; truncated or damaged gzip data ends like it does with the serial stream (exit 12)"""
