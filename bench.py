@@ -208,8 +208,13 @@ def main():
     # the headline steps and reported as `pageable_input`.
     pinned = None
     if not args.pageable_input:
-        pinned = M.HostBuffer(len(bases))
-        pinned.array[:] = bases
+        try:
+            pinned = M.HostBuffer(len(bases))
+            pinned.array[:] = bases
+        except M.MtsvError as e:  # no page-locked memory to be had: time the staged route and say so
+            print(f"bench: mtsv_host_alloc failed ({e}); timing reads in ordinary memory", file=sys.stderr)
+            pinned = None
+            args.pageable_input = True
     bases_p, off_p = (pinned.array if pinned else bases).ctypes.data, off.ctypes.data
 
     split = [0.0, 0.0, 0.0]  # seconds inside mtsv_batch_run_host / mtsv_batch_download / mtsv_hits_free over the timed steps
