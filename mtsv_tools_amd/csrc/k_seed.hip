@@ -328,7 +328,6 @@ __global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases,
     for (uint32_t j = 0; j < ns; j++) {
         uint64_t offset = (uint64_t)j * G;
         uint32_t c = cnt[j];
-        pre[j] = total;  // hits of the strand's earlier kept seeds (k_expand's output offset)
         if (offset < next_offset) {  // index.rs:300-302
             if (c) cnt[j] = 0;
             continue;
@@ -342,6 +341,7 @@ __global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases,
             seed_interval *= 2;
             next_offset = offset + seed_interval;
         }
+        pre[j] = total;  // hits of the strand's earlier kept seeds: k_expand's output offset (it reads the entries of kept seeds only)
         total += c;
         nseeds++;
     }
