@@ -357,7 +357,7 @@ class GzFastx {
         fastq_ = fastq;
         block_ = std::max<uint64_t>(block_bytes, 1);
         threads_ = std::max(1u, threads);
-        uint64_t chunk = 4ull << 20;  // compressed bytes per inflater thread and round
+        uint64_t chunk = 2ull << 20;  // compressed bytes per inflater chunk (two chunks per thread and round)
         if (const char* e = getenv("MTSV_PGZIP_CHUNK")) chunk = strtoull(e, nullptr, 10);
         if (!gz_.open(path, threads_, chunk)) return false;
         window_ = 2 * threads_ + 2;

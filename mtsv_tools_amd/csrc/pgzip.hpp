@@ -29,7 +29,9 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <functional>
 #include <cstdio>
 #include <cstdlib>
 #include <cstdint>
@@ -543,7 +545,7 @@ inline uint64_t find_entry_point(const uint8_t* base, const uint8_t* end, uint64
 class ParallelGunzip {
    public:
     ~ParallelGunzip() { close(); }
-    bool open(const std::string& path, unsigned threads, uint64_t chunk_bytes = 4ull << 20) {
+    bool open(const std::string& path, unsigned threads, uint64_t chunk_bytes = 2ull << 20) {
         threads_ = std::max(1u, threads);
         chunk_ = std::max<uint64_t>(chunk_bytes, 64 * 1024);
         fd_ = ::open(path.c_str(), O_RDONLY);
@@ -578,22 +580,30 @@ class ParallelGunzip {
         if (done_) return true;
         const uint8_t* end = data_ + size_;
         const uint64_t first_byte = pos_bit_ >> 3;
-        const unsigned T = (unsigned)std::min<uint64_t>(threads_, std::max<uint64_t>(1, (size_ - first_byte + chunk_ - 1) / chunk_));
+        // twice as many chunks as threads, handed out from a counter: the chunks of a round take unequal time, and a
+        // thread per chunk left the fast ones waiting at every one of the round's three barriers
+        const unsigned T = (unsigned)std::min<uint64_t>(2ull * threads_, std::max<uint64_t>(1, (size_ - first_byte + chunk_ - 1) / chunk_));
+        auto for_each = [&](size_t n, size_t first, const std::function<void(size_t)>& fn) {
+            std::atomic<size_t> next{first};
+            auto work = [&] {
+                for (size_t k; (k = next.fetch_add(1)) < n;) fn(k);
+            };
+            std::vector<std::thread> th;
+            const size_t nt = std::min<size_t>(threads_, n > first ? n - first : 0);
+            for (size_t t = 1; t < nt; t++) th.emplace_back(work);
+            if (nt) work();
+            for (auto& t : th) t.join();
+        };
         const bool trace = getenv("MTSV_PGZIP_TRACE") != nullptr;
         auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double t0 = now();
         // 1. entry points (chunk 0 starts at pos_bit_)
         std::vector<uint64_t> entry(T, ~0ull);
         entry[0] = pos_bit_;
-        {
-            std::vector<std::thread> th;
-            for (unsigned i = 1; i < T; i++)
-                th.emplace_back([&, i] {
-                    const uint64_t from = (first_byte + i * chunk_) * 8;
-                    entry[i] = find_entry_point(data_, end, from, std::min<uint64_t>(from + chunk_ * 8, size_ * 8));
-                });
-            for (auto& t : th) t.join();
-        }
+        for_each(T, 1, [&](size_t i) {
+            const uint64_t from = (first_byte + i * chunk_) * 8;
+            entry[i] = find_entry_point(data_, end, from, std::min<uint64_t>(from + chunk_ * 8, size_ * 8));
+        });
         const double t1 = now();
         const uint64_t limit_bits = std::min<uint64_t>((first_byte + (uint64_t)T * chunk_) * 8, size_ * 8);
         // 2. inflate every chunk up to the next valid entry point (symbol buffers are kept from round to round:
@@ -622,12 +632,7 @@ class ParallelGunzip {
         std::vector<unsigned> order;  // chunks that take part, in file order
         for (unsigned i = 0; i < T; i++)
             if (entry[i] != ~0ull) order.push_back(i);
-        {
-            std::vector<std::thread> th;
-            for (size_t k = 0; k < order.size(); k++)
-                th.emplace_back([&, k] { inflate_chunk(order[k], k + 1 < order.size() ? order[k + 1] : T); });
-            for (auto& t : th) t.join();
-        }
+        for_each(order.size(), 0, [&](size_t k) { inflate_chunk(order[k], k + 1 < order.size() ? order[k + 1] : T); });
         // chains: chunk order[k] must have stopped AT_TARGET on order[k+1]; if it ran past it (a false entry point),
         // it carries on to the one after (serially: rare)
         const double t2 = now();
@@ -672,10 +677,7 @@ class ParallelGunzip {
         pieces.resize(kept.size());
         std::vector<std::vector<std::pair<uint32_t, uint64_t>>> crcs(kept.size());  // per chunk: (crc, length) of every member part
         std::vector<std::string> errs(kept.size());
-        {
-            std::vector<std::thread> th;
-            for (size_t k = 0; k < kept.size(); k++)
-                th.emplace_back([&, k] {
+        for_each(kept.size(), 0, [&](size_t k) {
                     const Chunk& c = ch[kept[k]];
                     const std::vector<uint8_t>& pw = win[k];
                     std::vector<uint8_t>& o = pieces[k];
@@ -715,9 +717,7 @@ class ParallelGunzip {
                         from = m.end_symbol;
                     }
                     crcs[k].emplace_back(crc_of(o.data() + from, n - from), n - from);
-                });
-            for (auto& t : th) t.join();
-        }
+        });
         for (auto& e : errs)
             if (!e.empty()) return fail(e);
         // member CRCs across chunks
@@ -775,7 +775,7 @@ class ParallelGunzip {
     }
     int fd_ = -1;
     const uint8_t* data_ = nullptr;
-    uint64_t size_ = 0, chunk_ = 4 << 20, pos_bit_ = 0, member_len_ = 0;
+    uint64_t size_ = 0, chunk_ = 2 << 20, pos_bit_ = 0, member_len_ = 0;
     unsigned threads_ = 1;
     std::vector<uint8_t> window_;
     uint32_t crc_ = 0;
