@@ -444,7 +444,30 @@ int mtsv_format_results(const mtsv_hit* hits, uint64_t n_hits, const char* ids, 
                         int long_format, char** out, uint64_t* out_len) {
     if ((!hits && n_hits) || !ids || !id_off || !out || !out_len) return fail_arg("null argument");
     GUARD({
-        std::string buf;
+        // the text grows in a malloc'd buffer that is handed to the caller as it is; numbers are written digit by
+        // digit (snprintf per TaxID cost more than everything else on the result side of mtsv-binner)
+        struct Text {
+            char* p = nullptr;
+            uint64_t n = 0, cap = 0;
+            ~Text() { free(p); }
+            void room(uint64_t more) {
+                if (n + more <= cap) return;
+                const uint64_t ncap = std::max<uint64_t>(n + more, cap + cap / 2 + (1 << 16));
+                char* q = (char*)realloc(p, ncap);
+                if (!q) throw std::bad_alloc();
+                p = q;
+                cap = ncap;
+            }
+            void put(uint64_t v) {  // decimal, as %u / %llu
+                char tmp[20];
+                int k = 0;
+                do {
+                    tmp[k++] = (char)('0' + v % 10);
+                    v /= 10;
+                } while (v);
+                while (k) p[n++] = tmp[--k];
+            }
+        } buf;
         struct Item {
             uint32_t tax, gi;
             uint64_t off;
@@ -452,7 +475,6 @@ int mtsv_format_results(const mtsv_hit* hits, uint64_t n_hits, const char* ids, 
         };
         std::vector<Item> items;
         uint64_t i = 0;
-        char num[96];
         while (i < n_hits) {
             uint64_t r = hits[i].read;
             if (r >= n_reads) throw std::runtime_error("arg: hit refers to a read outside the batch");
@@ -484,27 +506,33 @@ int mtsv_format_results(const mtsv_hit* hits, uint64_t n_hits, const char* ids, 
                     if (a.tax != b.tax) return a.tax < b.tax;
                     return a.edit < b.edit;
                 });
-            buf.append(ids + id_off[r], strnlen(ids + id_off[r], id_off[r + 1] - id_off[r]));
-            buf.push_back(':');
+            const uint64_t id_len = strnlen(ids + id_off[r], id_off[r + 1] - id_off[r]);
+            buf.room(id_len + 2 + items.size() * 56 + 1);  // "tax-gi-offset=edit," is at most 10 + 1 + 10 + 1 + 20 + 1 + 10 + 1 characters
+            memcpy(buf.p + buf.n, ids + id_off[r], id_len);
+            buf.n += id_len;
+            buf.p[buf.n++] = ':';
             bool first = true;
             for (auto& it : items) {
-                if (!first) buf.push_back(',');
+                if (!first) buf.p[buf.n++] = ',';
                 first = false;
-                if (long_format)
-                    snprintf(num, sizeof num, "%u-%u-%llu=%u", it.tax, it.gi, (unsigned long long)it.off, it.edit);
-                else
-                    snprintf(num, sizeof num, "%u=%u", it.tax, it.edit);
-                buf.append(num);
+                buf.put(it.tax);
+                if (long_format) {  // "%u-%u-%llu=%u"
+                    buf.p[buf.n++] = '-';
+                    buf.put(it.gi);
+                    buf.p[buf.n++] = '-';
+                    buf.put(it.off);
+                }
+                buf.p[buf.n++] = '=';
+                buf.put(it.edit);
             }
-            buf.push_back('\n');
+            buf.p[buf.n++] = '\n';
             i = j;
         }
-        char* o = (char*)malloc(buf.size() + 1);
-        if (!o) throw std::bad_alloc();
-        memcpy(o, buf.data(), buf.size());
-        o[buf.size()] = 0;
-        *out = o;
-        *out_len = buf.size();
+        buf.room(1);
+        buf.p[buf.n] = 0;
+        *out = buf.p;
+        *out_len = buf.n;
+        buf.p = nullptr;  // the caller's now (mtsv_free)
     })
 }
 
