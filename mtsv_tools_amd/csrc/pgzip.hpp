@@ -251,7 +251,7 @@ using SymVec = std::vector<uint16_t, NoInit<uint16_t>>;
 struct Symbols {
     SymVec s;
     uint64_t member_start = 0;  // symbols before this index belong to an earlier gzip member
-    uint64_t marker_end = 0;    // no symbol at or after this index is a window reference
+    uint64_t marker_end = 0;    // no symbol at or after this index is a window reference (an upper bound of the last one)
 };
 
 struct Member {  // a member that ended inside a chunk
@@ -360,10 +360,9 @@ struct Inflater {
             } else {
                 for (uint32_t j = 0; j < len; j++) o[j] = src[j];
             }
-            if (may_mark) {
-                for (uint32_t j = 0; j < len; j++)
-                    if (o[j] >= 256) out->marker_end = n0 + j + 1;
-            }
+            // (an upper bound, not a scan: the resolve pass maps everything below marker_end through one table, which
+            //  leaves plain bytes alone; in FASTQ the references live on to the end of a chunk anyway)
+            if (may_mark) out->marker_end = n0 + len;
             if (VALIDATE && text_only)
                 for (uint32_t j = 0; j < len; j++)
                     if (o[j] < 256 && !is_text(o[j])) return fail("binary data");
