@@ -99,6 +99,44 @@ def test_format_results_equals_reference_vectors_and_oracle():
         assert M.format_results(h, ids, long_fmt) == want
 
 
+def test_format_results_numbers_at_their_limits_and_many_lines():
+    """the formatter writes its digits itself (binner.rs:326-379 formats with {}): every width of u32 / u64 including the
+    largest values, zero, duplicates folded to the smallest edit, against Python's own formatting of the same rule"""
+    rng = np.random.default_rng(3)
+    n_reads = 5000
+    edges32 = [0, 1, 9, 10, 99, 100, 999999999, 1000000000, 2**31 - 1, 2**31, 2**32 - 1]
+    edges64 = [0, 9, 10, 2**32 - 1, 2**32, 10**18, 2**63, 2**64 - 1]
+    rows = []
+    for r in range(n_reads):
+        for _ in range(int(rng.integers(0, 4))):
+            tax = int(rng.choice(edges32)) if rng.random() < 0.5 else int(rng.integers(0, 2**32))
+            gi = int(rng.choice(edges32)) if rng.random() < 0.5 else int(rng.integers(0, 2**32))
+            off = int(rng.choice(np.array(edges64, dtype=np.uint64))) if rng.random() < 0.5 else int(rng.integers(0, 2**63))
+            edit = int(rng.choice(edges32)) if rng.random() < 0.3 else int(rng.integers(0, 40))
+            rows.append((r, tax, gi, edit, int(rng.integers(0, 2)), off))
+            if rng.random() < 0.3:  # the same key again with another edit
+                rows.append((r, tax, gi, int(rng.integers(0, 40)), 1, off))
+    hits = np.zeros(len(rows), dtype=M.HIT_DTYPE)
+    for k, (r, tax, gi, edit, strand, off) in enumerate(rows):
+        hits[k] = (r, tax, gi, edit, strand, off)
+    ids = [f"read/{i} x" if i % 7 else "" for i in range(n_reads)]
+    for long_format in (False, True):
+        want = []
+        for r in range(n_reads):
+            best = {}
+            for (rr, tax, gi, edit, _, off) in rows:
+                if rr != r:
+                    continue
+                key = (tax, gi, off) if long_format else (tax,)
+                best[key] = min(best.get(key, edit), edit)
+            if not best:
+                continue
+            items = sorted(best.items())
+            body = ",".join((f"{k[0]}-{k[1]}-{k[2]}={e}" if long_format else f"{k[0]}={e}") for k, e in items)
+            want.append(f"{ids[r]}:{body}\n")
+        assert M.format_results(hits, ids, long_format) == "".join(want)
+
+
 def test_format_results_rejects_unordered_hits():
     h = np.zeros(2, dtype=M.HIT_DTYPE)
     h["read"] = [1, 0]
