@@ -418,11 +418,25 @@ struct Inflater {
             const uint32_t k = FastHuff::kind_of(e);
             if (k == FastHuff::END) return !br.overrun_now() || fail("truncated");
             if (k != FastHuff::BASE) return fail("bad literal/length symbol");
-            const uint32_t len = FastHuff::value_of(e) + br.get((int)FastHuff::extra_of(e));
-            br.refill();
+            // (at least 5 bits are left for the length's extra bits: the symbol was decoded from 20 or more)
+            const uint32_t lx = FastHuff::extra_of(e);
+            const uint32_t len = FastHuff::value_of(e) + br.peek((int)lx);
+            br.consume((int)lx);
+            if (br.cnt < 28) br.refill();  // a distance code and its extra bits: 15 + 13
             const uint32_t de = decode(dist);
             if (FastHuff::kind_of(de) != FastHuff::BASE) return fail("bad distance symbol");
-            const uint32_t d = FastHuff::value_of(de) + br.get((int)FastHuff::extra_of(de));
+            const uint32_t dx = FastHuff::extra_of(de);
+            const uint32_t d = FastHuff::value_of(de) + br.peek((int)dx);
+            br.consume((int)dx);
+            // the common case inline: the source lies inside the chunk and its member, eight or more symbols back
+            if (!VALIDATE && d >= 8 && d <= n_ - out->member_start) {
+                uint16_t* q = o + n_;
+                const uint16_t* src = q - d;
+                for (uint32_t j = 0; j < len; j += 8) memcpy(q + j, src + j, 16);
+                if (n_ - d < out->marker_end) out->marker_end = n_ + len;  // (an upper bound: see copy())
+                n_ += len;
+                continue;
+            }
             if (!copy<VALIDATE>(len, d)) return false;
             if (VALIDATE && br.overrun_now()) return fail("truncated");
         }
