@@ -140,6 +140,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     if (const char* e = getenv("MTSV_SW_DIAG")) sw_diag = atoi(e) != 0;
     if (const char* e = getenv("MTSV_SW_PREPASS")) sw_prepass = atoi(e) != 0;
     if (const char* e = getenv("MTSV_SW_TOP")) sw_top = atoi(e) != 0;
+    if (const char* e = getenv("MTSV_SW_BOUND")) sw_bound = atoi(e) != 0;
     verify_mode = g_default_verify_mode;
     if (const char* e = getenv("MTSV_VERIFY")) verify_mode = !strcmp(e, "edit_first") ? 1 : 0;
     for (auto& e : ev) HIP_CHECK(hipEventCreate(&e));
@@ -271,6 +272,7 @@ void Batch::begin_run(const mtsv_params& p) {
         l->sw_diag = sw_diag;
         l->sw_prepass = sw_prepass;
         l->sw_top = sw_top;
+        l->sw_bound = sw_bound;
         l->reset_lane();
     }
 }
@@ -574,17 +576,32 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                         sw.worklist = sweep_list;
                         sw.wl_count_slot = 16;
                         sw.wl_reverse = 0;  // k_sw_diag read the worklist from its end
-                        if (sw_top) {
-                            // most of these are refuted on the top half of the read rows; the full-height launch below
-                            // takes what is left ([17] counts it; the seed-hit rows of k_expand are free by now)
-                            HIP_CHECK(hipMemsetAsync(d_counters + 17, 0, sizeof(uint64_t), stream));
-                            sw.und_list = (uint32_t*)d_hit_row;
-                            sw.und_slot = 17;
-                            launch_sw_pairs(stream, v, sw, items, pass_max_len, false, true);
-                            HIP_CHECK(hipMemsetAsync(d_counters + 8, 0, sizeof(uint64_t), stream));  // the claim cursor
-                            sw.worklist = sw.und_list;
-                            sw.wl_count_slot = 17;
-                        }
+                    }
+                    if (round == 0 && sw_bound) {
+                        // What the lower bounds leave are mostly chance seed hits.  The unit-cost edit distance under the SW
+                        // matrix's matches bounds the score from both sides (k_edit_myers in bound mode) at a third of a
+                        // sweep's instructions: it refutes those, passes most of the rest, and only what lies between its
+                        // two thresholds ([17] counts it; the seed-hit rows of k_expand are free by now) is swept below.
+                        HIP_CHECK(hipMemsetAsync(d_counters + 17, 0, 2 * sizeof(uint64_t), stream));  // [18]: its claim cursor
+                        EvalArgs bd = sw;
+                        bd.wl_count = (const uint32_t*)(d_counters + sw.wl_count_slot);
+                        bd.wl_cursor = (uint32_t*)(d_counters + 18);
+                        bd.und_list = (uint32_t*)d_hit_row;
+                        bd.und_slot = 17;
+                        launch_edit_myers(stream, v, bd, items, pass_max_len, 2);
+                        sw.worklist = bd.und_list;
+                        sw.wl_count_slot = 17;
+                        sw.wl_reverse = 0;
+                    } else if (round == 0 && sw_diag && sw_prepass && sw_top) {
+                        // (MTSV_SW_BOUND=0) most of these are refuted on the top half of the read rows; the full-height launch
+                        // below takes what is left ([17] counts it)
+                        HIP_CHECK(hipMemsetAsync(d_counters + 17, 0, sizeof(uint64_t), stream));
+                        sw.und_list = (uint32_t*)d_hit_row;
+                        sw.und_slot = 17;
+                        launch_sw_pairs(stream, v, sw, items, pass_max_len, false, true);
+                        HIP_CHECK(hipMemsetAsync(d_counters + 8, 0, sizeof(uint64_t), stream));  // the claim cursor
+                        sw.worklist = sw.und_list;
+                        sw.wl_count_slot = 17;
                     }
                     launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag);
 #ifdef MTSV_SW_HIST
@@ -608,7 +625,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     my.wl_cursor = (uint32_t*)(d_counters + 10);
                     my.next_list = next_lists[round & 1];
                     my.next_count = (uint32_t*)next_slot;
-                    launch_edit_myers(stream, v, my, items, pass_max_len, true);
+                    launch_edit_myers(stream, v, my, items, pass_max_len, 1);
                     HIP_CHECK(hipMemcpyAsync(h_counters + 11, next_slot, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipMemcpyAsync(h_counters + 9, d_counters + 9, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
                     HIP_CHECK(hipStreamSynchronize(stream));

@@ -73,6 +73,7 @@ struct Batch {
     static constexpr int kCounters = 24;
     bool sw_diag = true;   // k_sw_pairs tries the ungapped diagonal as a lower bound first (MTSV_SW_DIAG=0: off)
     bool sw_top = true;      // ... and what they leave is swept on the top half of the read rows first (MTSV_SW_TOP=0: off)
+    bool sw_bound = true;    // ... first by the edit-distance bound on the score (k_edit_myers in bound mode; MTSV_SW_BOUND=0: off)
     bool sw_prepass = true;  // the first round's bounds run as a kernel of their own, k_sw_diag (MTSV_SW_PREPASS=0: inside k_sw_pairs)
     bool sw_pairs = true;  // reference order for reads <= 253 bases: k_sw_pairs + k_edit_myers (MTSV_SW=packed: k_evaluate)
     int verify_mode = 0;  // 0 = reference order (SW + edit per candidate), 1 = edit first (MTSV_VERIFY_EDIT_FIRST)

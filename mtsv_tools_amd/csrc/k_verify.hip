@@ -1268,6 +1268,14 @@ __device__ inline uint32_t clamp_codes4(uint32_t x) {
     const uint32_t t = x & 0x04040404u;
     return t | (x & 0x03030303u & ~((t >> 1) | (t >> 2)));
 }
+// the same for the SW-semantics bound (k_edit_myers in bound mode): N stays N (it matches a read N, ssw/src/lib.rs:11-16),
+// everything above ('$', padding) becomes 5 = matches nothing
+__device__ inline uint32_t clamp_codes6(uint32_t x) {
+    const uint32_t t = x & 0x04040404u, lo = x & 0x03030303u;
+    const uint32_t nz = (lo | (lo >> 1)) & 0x01010101u, m = t >> 2;
+    return t | (lo & ~(m * 3u)) | (nz & m);
+}
+template <bool KEEP_N = false>
 __device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint32_t end, uint32_t strand, uint32_t j0) {
     uint4 r;
     if (!strand) {
@@ -1286,10 +1294,10 @@ __device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint3
         }
         r = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    r.x = clamp_codes4(r.x);
-    r.y = clamp_codes4(r.y);
-    r.z = clamp_codes4(r.z);
-    r.w = clamp_codes4(r.w);
+    r.x = KEEP_N ? clamp_codes6(r.x) : clamp_codes4(r.x);
+    r.y = KEEP_N ? clamp_codes6(r.y) : clamp_codes4(r.y);
+    r.z = KEEP_N ? clamp_codes6(r.z) : clamp_codes4(r.z);
+    r.w = KEEP_N ? clamp_codes6(r.w) : clamp_codes4(r.w);
     return r;
 }
 
@@ -1302,9 +1310,26 @@ __device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint3
 // the last row) with Myers' bit-vector recurrence, one lane per candidate, W 32-bit words per
 // column, match masks in LDS.  Read 'N' matches nothing (index.rs:272-279), reference 'N' matches nothing either.
 // ---------------------------------------------------------------------------------------------
-// LIST: the items are single candidates that already passed the SW prefilter (k_sw_pairs); one that
+// MY_LIST: the items are single candidates that already passed the SW prefilter (k_sw_pairs); one that
 // fails index.rs:410 hands its TaxId's next candidate to the next round instead of walking on.
-template <int W, bool LIST>  // W 32-bit words per column: reads of up to 32*W bases
+//
+// MY_BOUND: the same recurrence as a two-sided bound on the SW prefilter's predicate (index.rs:406), for the candidates
+// k_sw_diag's lower bounds left undecided -- nearly all of them chance seed hits that the DP sweep of k_sw_pairs
+// refutes at several times the cost.  Matches are the SW matrix's (ssw/src/lib.rs:11-16: equal codes, a read N facing
+// a window N included); D = the unit-cost semi-global distance of the read to the window under those matches.
+//   (1) D <= ED  =>  score >= L - 2*ED.  The alignment behind D has m mismatches, i read bases and d window bases
+//       against gaps, m + i + d = D, and L - m - i matches: as a local alignment it scores
+//       (L - m - i) - m - i - d >= L - 2*D  (+1 match, -1 mismatch, a gap of g costs g).
+//   (2) score >= L - 2*ED  =>  D <= 2*ED.  The best local alignment leaves u read rows uncovered and has M matches,
+//       m mismatches, i and d gap bases: L = u + M + m + i and score = M - m - i - d = L - u - 2m - 2i - d.
+//       Extended by the u uncovered read bases as insertions it is a semi-global alignment of the whole read with
+//       u + m + i + d <= u + 2m + 2i + d = L - score <= 2*ED unit edits.
+// So D <= ED passes the candidate on to the edit distance, D > 2*ED refutes it (its TaxId's next candidate is then
+// bounded by the same lane, index.rs:393), and the few in between go to und_list for the sweep.  A chance candidate
+// sits near D = 0.4*L, far above 2*ED = 0.26*L.  A lane leaves the columns early once D <= ED is reached, or once the
+// last row can no longer come down to 2*ED in the columns that are left (neighbouring cells differ by at most 1).
+enum : int { MY_CHAIN = 0, MY_LIST = 1, MY_BOUND = 2 };
+template <int W, int MODE>  // W 32-bit words per column: reads of up to 32*W bases
 __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a) {
     // match masks of the lane's read, one row per window symbol (A C G T, other), word-major so that a
     // lane's reads are conflict-free whatever row it picks.  The read sits at the TOP of the 32*W rows
@@ -1312,7 +1337,9 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     // start at 0: they stay 0 in every column, i.e. they reproduce the all-zero first row of
     // align.rs:28-85 right under the read's first base, and the running score is simply the carry out
     // of the last word.
-    __shared__ uint32_t eq_tab[5][W][256];
+    constexpr bool LIST = MODE == MY_LIST, BOUND = MODE == MY_BOUND;
+    constexpr int NROW = BOUND ? 6 : 5;  // bound mode: N is a symbol of its own, row 5 = matches nothing
+    __shared__ uint32_t eq_tab[NROW][W][256];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_work = *a.wl_count;
     const uint32_t maxc = a.maxc;  // max_candidates as a rank bound, clamped on the host
@@ -1324,6 +1351,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     // and moves to the next candidate of the same TaxId (index.rs:393)
     uint32_t bnext = 0, bend = 0;
     bool active = false, exhausted = false;
+    bool counted = false;  // bound mode: k_sw_diag has counted this candidate (verified, window bytes)
     uint32_t g = 0, o = 0, L = 0, ED = 0, strand = 0;
     bool thr_wrapped = false, hopeless = false;
     uint32_t pv0[W];  // vertical +1 deltas of column 0: the read's rows only
@@ -1345,6 +1373,10 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             const uint32_t take = bnext + __popcll(need & ((1ull << lane) - 1));
             if (!active && take < bend) {
                 g = a.worklist[take];
+                if (BOUND) {
+                    counted = (g & kSweepFlag) != 0;
+                    g &= ~kSweepFlag;
+                }
                 const uint32_t rs = a.cand[g].w;
                 const uint32_t r_ = a.r0 + (rs >> 1);
                 strand = rs & 1;
@@ -1394,11 +1426,13 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     eq_tab[1][k][tid] = (strand ? mG : mC) | wild;
                     eq_tab[2][k][tid] = (strand ? mC : mG) | wild;
                     eq_tab[3][k][tid] = (strand ? mA : mT) | wild;
-                    eq_tab[4][k][tid] = wild;
+                    // every read position that is no base is an N (k_normalise): it matches a window N in the SW matrix only
+                    eq_tab[4][k][tid] = BOUND ? ~(mA | mC | mG | mT) : wild;
+                    if (BOUND) eq_tab[NROW - 1][k][tid] = wild;
                     pv0[k] = ~wild;
                 }
                 // edits >= number of read positions that match nothing (N): see k_evaluate
-                hopeless = thr_wrapped || L - matchable > ED;
+                hopeless = thr_wrapped || (!BOUND && L - matchable > ED);
                 active = true;
             }
             bnext = min(bnext + (uint32_t)__popcll(need), bend);
@@ -1407,17 +1441,20 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             if (exhausted) break;
             continue;
         }
+        uint32_t verdict = 0, vg = 0;  // bound mode: 1 = passes the prefilter, 2 = undecided (candidate vg)
         if (!LIST && active && hopeless) {  // no sweep needed: every candidate of this strand fails
             const uint4 c = a.cand[g];
-            verified++;
-            wbytes += c.y - c.x;
+            if (!BOUND || !counted) {
+                verified++;
+                wbytes += c.y - c.x;
+            }
+            counted = false;
             a.cand_status[g] = 1;
             const uint32_t nxt = a.cand_next[g];
             if (nxt == 0xffffffffu || nxt >= maxc) active = false;
             else g = o + nxt;
         } else if (active) {
             const uint4 c = a.cand[g];
-            const DevBin bin = ix.bins[c.z];
             uint32_t Pv[W], Mv[W];
 #pragma unroll
             for (int k = 0; k < W; k++) {
@@ -1426,11 +1463,15 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             }
             const uint32_t Wn = c.y - c.x;
             int score = (int)L, best = (int)L;  // D[L][0] = L
-            uint4 nxt4 = Wn ? fetch_cols(ix, c.x, c.y, strand, 0) : make_uint4(0, 0, 0, 0);
+            uint4 nxt4 = Wn ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 0) : make_uint4(0, 0, 0, 0);
             const uint32_t* lane_tab = &eq_tab[0][0][tid];
             for (uint32_t j0 = 0; j0 < Wn; j0 += 16) {
+                if (BOUND) {  // decided already: passes, or the last row cannot come down to 2*ED any more
+                    if (best <= (int)ED) break;
+                    if (best > 2 * (int)ED && score - (int)(Wn - j0) > 2 * (int)ED) break;
+                }
                 const uint4 cur = nxt4;
-                if (j0 + 16 < Wn) nxt4 = fetch_cols(ix, c.x, c.y, strand, j0 + 16);  // prefetch the next 16 columns
+                if (j0 + 16 < Wn) nxt4 = fetch_cols<BOUND>(ix, c.x, c.y, strand, j0 + 16);  // prefetch the next 16 columns
                 const uint32_t lim = min(16u, Wn - j0);
 #pragma unroll
                 for (int jj = 0; jj < 16; jj++) {
@@ -1461,13 +1502,31 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     }
                 }
             }
-            if (!LIST) {
+            if (!LIST && (!BOUND || !counted)) {
                 verified++;
                 wbytes += Wn;
             }
+            counted = false;  // a TaxId's next candidate has not been counted by anyone
             const uint32_t ed = (uint32_t)best;
+            if (BOUND) {
+                if (!thr_wrapped && ed <= ED) {
+                    verdict = 1;
+                    vg = g;
+                    active = false;
+                } else if (!thr_wrapped && ed <= 2 * ED) {
+                    verdict = 2;
+                    vg = g;
+                    active = false;
+                } else {  // refuted: index.rs:406 fails
+                    a.cand_status[g] = 1;
+                    const uint32_t nxt = a.cand_next[g];
+                    if (nxt == 0xffffffffu || nxt >= maxc) active = false;
+                    else g = o + nxt;
+                }
+            } else {
             const bool pass = !thr_wrapped && ed <= ED;
             if (pass) {
+                const DevBin bin = ix.bins[c.z];
                 a.out[g] = make_uint4(bin.tax_id, bin.gi, c.x >= bin.start ? c.x - bin.start : 0, ed);
                 a.cand_status[g] = 2;
                 active = false;
@@ -1479,6 +1538,23 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     a.next_list[atomicAdd(a.next_count, 1u)] = o + nxt;
                     active = false;
                 } else g = o + nxt;
+            }
+            }
+        }
+        if (BOUND) {  // the wavefront's decisions of this trip: one atomic per list
+            const unsigned long long pm = __ballot(verdict == 1), um = __ballot(verdict == 2);
+            const unsigned long long lower = (1ull << lane) - 1ull;
+            if (pm) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(sw_pass_count(a), (uint32_t)__popcll(pm));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (verdict == 1) a.pass_list[base + (uint32_t)__popcll(pm & lower)] = vg;
+            }
+            if (um) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(reinterpret_cast<uint32_t*>(a.counters + a.und_slot), (uint32_t)__popcll(um));
+                base = __builtin_amdgcn_readfirstlane(base);
+                if (verdict == 2) a.und_list[base + (uint32_t)__popcll(um & lower)] = vg | kSweepFlag;  // counted, bounds tried
             }
         }
     }
@@ -1630,15 +1706,16 @@ void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, ui
 }
 
 void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len,
-                       bool list_mode) {
+                       int mode) {
     EvalArgs a = a_;
     a.maxc = rank_bound(a.max_candidates);
     uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256), 256 * 8));
     uint32_t W = (max_len + 31) / 32;
 #define MYERS_CASE(WW)                                                                                   \
     do {                                                                                                 \
-        if (list_mode) hipLaunchKernelGGL((k_edit_myers<WW, true>), dim3(blocks), dim3(256), 0, s, ix, a);  \
-        else hipLaunchKernelGGL((k_edit_myers<WW, false>), dim3(blocks), dim3(256), 0, s, ix, a);           \
+        if (mode == MY_LIST) hipLaunchKernelGGL((k_edit_myers<WW, MY_LIST>), dim3(blocks), dim3(256), 0, s, ix, a);        \
+        else if (mode == MY_BOUND) hipLaunchKernelGGL((k_edit_myers<WW, MY_BOUND>), dim3(blocks), dim3(256), 0, s, ix, a); \
+        else hipLaunchKernelGGL((k_edit_myers<WW, MY_CHAIN>), dim3(blocks), dim3(256), 0, s, ix, a);                      \
     } while (0)
     if (W <= 2) MYERS_CASE(2);
     else if (W <= 3) MYERS_CASE(3);

@@ -111,9 +111,13 @@ void launch_evaluate_tiled(hipStream_t s, const DevIndexView& ix, const EvalArgs
 uint32_t tiled_groups(uint64_t max_items, uint32_t strip_len);
 void launch_max_window(hipStream_t s, uint32_t n_strands, const uint32_t* strand_off, const uint32_t* strand_ncand,
                        const uint4* cand, unsigned long long* out);
-// edit-first order (reads up to 253 bases): Myers bit-vector edit distance, lane per candidate
+// Myers bit-vector edit distance, lane per candidate (reads up to 253 bases).
+// mode 0: edit-first order over the same-TaxId chains; 1: the candidates of a.worklist that passed the SW prefilter
+// (reference order); 2: the recurrence as a two-sided bound on the prefilter's predicate itself -- what it proves to
+// pass goes to a.pass_list, what it refutes is marked failed (and the TaxId's next candidate bounded), the rest goes
+// to a.und_list (count in the low word of counter slot a.und_slot), flagged, for launch_sw_pairs; a.counters set
 void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
-                       bool list_mode = false);
+                       int mode = 0);
 // reference order for reads <= 253 bases: SW prefilter alone, two candidates per 16-lane group
 // diag = false: without the lower bounds on the seed diagonal (every candidate that is not hopeless is swept)
 // top = true: the sweep on the top half of the read rows (k_sw_pairs<R/2, false, TOP>): refutes or passes what those rows

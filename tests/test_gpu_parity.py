@@ -535,8 +535,10 @@ def test_prefilter_shortcuts_for_every_row_count(tricky, max_len, monkeypatch):
     # the instantiation without the lower bounds on the seed diagonal (every candidate that is not hopeless is
     # swept) decides every candidate the same way: same hits, same counters, more cells
     monkeypatch.setenv("MTSV_SW_DIAG", "0")
+    monkeypatch.setenv("MTSV_SW_BOUND", "0")
     b = M.Batch(ix, 0, len(reads), len(bases))
     monkeypatch.delenv("MTSV_SW_DIAG")
+    monkeypatch.delenv("MTSV_SW_BOUND")
     b.upload(bases, off)
     b.run(mp)
     assert_same_hits(b.download(), want)
@@ -576,17 +578,20 @@ def test_lanes_do_not_change_hits_or_counters(medium, monkeypatch):
 
 
 def test_prefilter_stages_decide_alike(medium, tricky, monkeypatch):
-    """The SW prefilter of index.rs:406 runs as three kernels in the first round of a pass -- the bounds on the seed
-    diagonal (k_sw_diag), the sweep on the top half of the read rows (k_sw_pairs TOP), the full-height sweep of
-    what is left -- or, with the environment switches below, as two or as one.  Every arrangement decides every
-    candidate alike: same hits, same candidates examined, same number sent on to the edit distance."""
+    """The SW prefilter of index.rs:406 runs as three kernels in the first round of a pass -- the lower bounds on the
+    seed diagonal (k_sw_diag), the two-sided bound by the unit-cost edit distance under the SW matrix's matches
+    (k_edit_myers in bound mode), the full-height sweep of what neither decides -- or, with the environment switches
+    below, with the top-half sweep (k_sw_pairs TOP) in the place of the second, as two kernels or as one.  Every
+    arrangement decides every candidate alike: same hits, same candidates examined, same number sent on to the edit
+    distance."""
     ix, bases, off = medium
     tix, _, treads = tricky
     tb, to = helpers.reads_to_batch([r for r in treads if len(r) <= 253])
     ref = {}
-    for prepass, top in (("0", "0"), ("1", "0"), ("1", "1")):
+    for prepass, top, bound in (("0", "0", "0"), ("1", "0", "0"), ("1", "1", "0"), ("1", "1", "1"), ("0", "0", "1")):
         monkeypatch.setenv("MTSV_SW_PREPASS", prepass)
         monkeypatch.setenv("MTSV_SW_TOP", top)
+        monkeypatch.setenv("MTSV_SW_BOUND", bound)
         for name, (x, b_, o_) in (("medium", (ix, bases, off)), ("tricky", (tix, tb, to))):
             x.to_device(0)
             b = M.Batch(x, 0, len(o_) - 1, len(b_))
@@ -599,8 +604,8 @@ def test_prefilter_stages_decide_alike(medium, tricky, monkeypatch):
                 ref[name] = got
                 assert got[1]["n_sw_passed"] >= got[1]["n_hits"] > 0
             assert_same_hits(got[0], ref[name][0])
-            assert got[1] == ref[name][1], (name, prepass, top)
-            if (prepass, top) == ("1", "1"):
+            assert got[1] == ref[name][1], (name, prepass, top, bound)
+            if (prepass, top, bound) == ("1", "1", "0"):
                 # the top-half sweep computes about half the cells of the full-height one (both count theirs)
                 assert 0 < st["sw_cell_pairs"]
 
