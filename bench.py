@@ -52,6 +52,35 @@ def algorithmic_bytes(ctr, n_reads):
     return stage, per
 
 
+def host_description():
+    """nproc, CPU model, and what this process may actually use of them (affinity, cgroup quota)."""
+    d = {"nproc": os.cpu_count()}
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                d["cpu_model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    d["affinity_cpus"] = len(os.sched_getaffinity(0))
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = int(txt[0]) / int(txt[1])
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    d["cgroup_cpu_quota"] = quota
+    return d
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -60,7 +89,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("MTSV_BENCH_WORKLOAD", "config2"))
     ap.add_argument("--reads", type=int, default=0, help="override reads per GPU per step")
     ap.add_argument("--cpu-sample", type=int, default=100000, help="reads timed on the CPU oracle")
-    ap.add_argument("--cpu-threads", type=int, default=16, help="OpenMP threads of the CPU baseline (the box's CPU share of one GPU)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="OpenMP threads of the CPU baseline (default: every CPU this process may use -- "
+                    "the GPU's NUMA node, capped by the cgroup's CPU quota)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
                     help="skip the device-resident leg and the other verify order (profiling runs)")
@@ -259,6 +289,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st_host = hb.stats()
+    split_timed = list(split)  # (the pageable leg below calls host_step again)
     hits = host_step(keep=True)  # untimed: the hits the parity checks below look at
     pageable = None
     if pinned is not None and not args.no_extras and rank == 0:
@@ -350,11 +381,16 @@ def main():
         from oracle import oracle as O
         ns = min(args.cpu_sample, n_reads)
         oix = O.Index.read(idx_path)
-        cores = max(1, min(ncpu, args.cpu_threads))
+        host = host_description()
+        usable = host["affinity_cpus"]
+        if host.get("cgroup_cpu_quota"):
+            usable = max(1, min(usable, int(round(host["cgroup_cpu_quota"]))))
+        cores = max(1, min(ncpu, args.cpu_threads or usable))
         t0 = time.perf_counter()
         ohits, ctr = oix.bin_batch(bases[: ns * read_len], off[: ns + 1], O.default_params(), threads=cores)
         dt = time.perf_counter() - t0
-        cpu = {"value": ns / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+        cpu = {"value": ns / dt, "unit": "reads/s", "cores": cores, "kind": "port", "host": host,
+               "cores_note": "every CPU this process may use: the CPUs of the GPU's NUMA node (affinity_cpus), capped by the cgroup's CPU quota",
                "sample": f"first {ns} reads of rank 0's batch, oracle/libmtsv_oracle.so (reference layout: byte BWT, "
                          f"Occ k=64, SA s=32, emulated striped SW, full-matrix edit DP), {cores} OpenMP threads, {dt:.1f} s"}
         stage_bytes, ctr_per = algorithmic_bytes(ctr, ns)
@@ -373,69 +409,82 @@ def main():
         raise SystemExit("bench: GPU hits differ from the oracle's: " + parity)
 
     # ---- roofline ----
-    # The dominant kernel is the SW prefilter k_sw_pairs (reference order, reads <= 253 bases).  It is bound by
-    # integer VALU issue, not by HBM: priced against the measured issue ceiling of the chip
-    # (profiles/r01_valu_issue_rate.txt: ~540 wave-instructions/us/SIMD for every integer op, 1024 SIMDs) with
-    # the USEFUL work only -- the packed 7-instruction recurrence of every DP cell pair the sweeps computed
-    # (device counter sw_cell_pairs; four 16-lane groups share one wave instruction) -- over its launch time
-    # (HIP events on the lane's stream, single-lane pass).  Its HBM figure in the contract's form (SURVEY 8d
-    # algorithmic bytes W per read over the same duration) and the pipeline's measured HBM traffic sit beside it.
-    VALU_PEAK = 1024 * 540e6  # wave-instructions per second
-    pre_ms = st1.get("sw_prefilter_ms", 0.0)          # k_sw_diag + the sweeps
-    sw_ms = st1.get("sw_sweep_ms", 0.0) or pre_ms      # the sweeps: k_sw_pairs on the top half of the rows, then at full height
-    dom = max((k for k in stage_ms if k != "total"), key=lambda k: stage_ms[k])
-    roof = {"bound": "valu", "kernel": "k_sw_pairs (the sweeps of the SW prefilter, index.rs:401-406)", "achieved": None, "peak": VALU_PEAK / 1e9,
-            "unit": "G wave-instr/s", "frac": None, "traffic": None, "kernel_ms": sw_ms, "prefilter_ms_with_k_sw_diag": pre_ms,
-            "share_of_resident_step": (sw_ms / stage_ms["total"]) if stage_ms.get("total") else None,
-            "peak_source": "tools/valu_rate.hip on this chip: 540 wave-instr/us/SIMD x 1024 SIMDs (profiles/r01_valu_issue_rate.txt)"}
-    if sw_ms > 0 and st1.get("sw_cell_pairs"):
-        useful = st1["sw_cell_pairs"] * 7 / 4.0
-        roof["achieved"] = useful / (sw_ms * 1e-3) / 1e9
-        roof["frac"] = roof["achieved"] / roof["peak"]
-        roof["useful_work"] = {"sw_cell_pairs": st1["sw_cell_pairs"], "valu_per_cell_pair": 7, "groups_per_wave": 4}
+    # Per-kernel times of one pass: HIP events on the lane's own stream, single-lane resident workspace (they agree
+    # with the rocprofv3 kernel trace under profiles/).  The largest kernel is priced against the roof that binds it:
+    #   k_search_fast  -- random 64-byte gathers in HBM (k-mer table entry + rank blocks): bound "hbm".  achieved =
+    #                     the bytes its own layout must touch per seed / its duration; `traffic` = FETCH_SIZE +
+    #                     WRITE_SIZE of the kernel from the PMC passes of the profiled run (profiles/hbm_traffic.json,
+    #                     which names the commit it was taken at); SURVEY 8(d)'s figure for the reference layout
+    #                     (64*2*X + L per read) sits beside it -- the table answers KK of a seed's K steps with one
+    #                     gather, so that figure is a work rate, not a fraction of the roof.
+    #   k_edit_myers   -- the bit-vector recurrences (edit-distance bound of the SW prefilter + edit distance): integer
+    #                     VALU issue.  Peak = the architectural 1024 SIMDs x one wave64 VALU instruction per 4 cycles
+    #                     at 2.4 GHz = 600 /us/SIMD; useful work = columns advanced (device counter) x W words x the
+    #                     12 instructions one word step of the recurrence needs on this ISA / 64 lanes.
+    VALU_PEAK = 1024 * 600e6  # wave-instructions per second
+    K_seed = params.seed_size
+    kk = info.get("kmer_k", 0)
+    W_words = (read_len + 31) // 32
+    kernels_ms = {"k_search": stage_ms["search"], "k_thin + scan": stage_ms["thin_scan"], "k_expand / k_locate": stage_ms["expand"] + stage_ms["locate"],
+                  "k_coalesce (+ _mid, _heavy)": stage_ms["coalesce"], "k_sw_diag": st1.get("sw_diag_ms", 0.0),
+                  "k_edit_myers (prefilter bound)": st1.get("sw_bound_ms", 0.0), "k_sw_pairs": st1.get("sw_sweep_ms", 0.0),
+                  "k_edit_myers (edit distance)": st1.get("edit_ms", 0.0), "scan + k_gather": stage_ms["gather"]}
+    prof = None
+    tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    if os.path.exists(tr):
+        try:
+            t = json.load(open(tr))
+            if t.get("workload") == args.workload and t.get("dev_flags") == args.dev_flags:
+                prof = t
+        except Exception:
+            prof = None
+    search_ms = stage_ms["search"]
+    seeds = st1["n_seed_slots"]
+    alg_search = seeds * (8 + 2 * 64 * max(0, K_seed - kk) + K_seed) if kk else None
+    roof = {"bound": "hbm", "kernel": f"k_search_fast<{kk}> (FMIndex::backward_search, index.rs:305)" if kk else "k_search",
+            "kernel_ms": search_ms, "share_of_resident_step": search_ms / stage_ms["total"] if stage_ms.get("total") else None,
+            "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
+            "kernels_ms": kernels_ms}
+    if alg_search and search_ms > 0:
+        roof["algorithmic_bytes_per_launch"] = alg_search
+        roof["algorithmic_model"] = (f"{seeds} seeds x (8 B k-mer table entry + {K_seed - kk} FM step(s) x 2 rank blocks of 64 B + {K_seed} B of read codes); "
+                                     "seeds whose table interval is empty skip the rank blocks, so this is an upper bound of what must be touched")
+        roof["achieved"] = alg_search / (search_ms * 1e-3) / 1e9
+        roof["frac"] = roof["achieved"] / PEAK_HBM_GBS
+    if prof and prof.get("k_search_bytes_per_step"):
+        roof["traffic"] = prof["k_search_bytes_per_step"]
+        roof["traffic_GBs_over_this_runs_time"] = prof["k_search_bytes_per_step"] / (search_ms * 1e-3) / 1e9
+        roof["traffic_source"] = {"file": "profiles/hbm_traffic.json", "from_profile_of_commit": prof.get("commit"),
+                                  "how": prof.get("source")}
+    my_ms = st1.get("sw_bound_ms", 0.0) + st1.get("edit_ms", 0.0)
+    valu = {"bound": "valu", "kernel": "k_edit_myers (bound mode + edit distance; index.rs:401-410, align.rs:28-85)", "kernel_ms": my_ms,
+            "peak": VALU_PEAK / 1e9, "unit": "G wave-instr/s",
+            "peak_source": "architectural: 1024 SIMDs x one wave64 VALU instruction per 4 cycles at 2.4 GHz (600 /us/SIMD); "
+                           "tools/valu_rate.hip measures 540-600 on this chip (profiles/r01_valu_issue_rate.txt)"}
+    if my_ms > 0 and st1.get("myers_columns"):
+        useful = st1["myers_columns"] * W_words * 12 / 64.0
+        valu["achieved"] = useful / (my_ms * 1e-3) / 1e9
+        valu["frac"] = valu["achieved"] / valu["peak"]
+        valu["useful_work"] = {"myers_columns": st1["myers_columns"], "words_per_column": W_words, "valu_per_word_step": 12, "lanes_per_wave": 64}
+    if prof and prof.get("k_edit_myers_valu_per_step") and my_ms > 0:
+        valu["issued_frac"] = prof["k_edit_myers_valu_per_step"] / (prof.get("k_edit_myers_ms_per_step") or my_ms) / 1e-3 / VALU_PEAK
+        valu["issued_source"] = {"file": "profiles/hbm_traffic.json", "from_profile_of_commit": prof.get("commit"),
+                                 "how": "SQ_INSTS_VALU of the k_edit_myers launches / their duration in the same profiled process"}
+    roof["valu"] = valu
     if stage_bytes is not None:
         res_ms = resident["ms_per_step"] if resident else stage_ms["total"]
-        hbm = {"bound": "hbm", "peak": PEAK_HBM_GBS, "unit": "GB/s",
-               "algorithmic_bytes_per_read": stage_bytes["total"],
-               "algorithmic_GBs_timed_region": stage_bytes["total"] * n_reads / (step_ms * 1e-3) / 1e9,
-               "algorithmic_GBs_resident_step": stage_bytes["total"] * n_reads / (res_ms * 1e-3) / 1e9,
-               "note": "algorithmic bytes = what the reference's own layout must touch (SURVEY 8d); the resident k-mer table and "
-                       "full suffix array avoid most of them, so this is a work rate, not a fraction of any roof"}
-        if sw_ms > 0:
-            hbm["dominant_kernel"] = {"name": "k_sw_pairs", "algorithmic_bytes_per_read": stage_bytes["verify"],
-                                      "achieved": stage_bytes["verify"] * n_reads / (sw_ms * 1e-3) / 1e9,
-                                      "frac": stage_bytes["verify"] * n_reads / (sw_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
-        per_stage = {}
-        for st_name, key in (("search", "search"), ("locate", "locate"), ("expand", "locate"), ("gather", "gather")):
-            if st_name == "expand" and stage_ms["locate"] > 0.05:
-                continue  # k_locate ran: the locate bytes belong to it
-            if st_name == "locate" and stage_ms["locate"] <= 0.05:
-                continue
-            ms = stage_ms[st_name]
-            if ms > 0:
-                per_stage[st_name] = {"ms": ms, "algorithmic_bytes_per_read": stage_bytes[key],
-                                      "algorithmic_GBs": stage_bytes[key] * n_reads / (ms * 1e-3) / 1e9}
-        hbm["per_stage"] = per_stage
-        tr = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tr):
-            try:
-                t = json.load(open(tr))
-                if t.get("workload") == args.workload and t.get("dev_flags") == args.dev_flags:
-                    # PMC counters of an earlier profiled run of this workload (rocprofv3 cannot wrap the driver's own run)
-                    hbm["measured_traffic_bytes_per_step"] = t["hbm_bytes_per_step"]
-                    hbm["measured_traffic_source"] = t.get("source")
-                    hbm["measured_frac_of_peak_resident_step"] = t["hbm_bytes_per_step"] / (res_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
-                    roof["traffic"] = t.get("k_sw_pairs_bytes_per_step")
-                    if t.get("k_search_bytes_per_step") and stage_ms.get("search"):
-                        # the second-largest kernel is bound by random 64-byte gathers in HBM (k-mer table, rank blocks)
-                        sb = t["k_search_bytes_per_step"]
-                        hbm["k_search"] = {"bound": "hbm", "ms": stage_ms["search"], "traffic": sb, "achieved": sb / (stage_ms["search"] * 1e-3) / 1e9,
-                                           "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": sb / (stage_ms["search"] * 1e-3) / 1e9 / PEAK_HBM_GBS,
-                                           "note": "measured FETCH_SIZE + WRITE_SIZE of k_search (raw counters of the profiled run, see measured_traffic_source) over its "
-                                                   "HIP-event time in this run; per seed one 8-byte gather in the k-mer table and two 64-byte rank blocks per FM step left"}
-            except Exception:
-                pass
-        roof["hbm"] = hbm
+        hbm = {"survey_8d_bytes_per_read": stage_bytes["total"],
+               "survey_8d_GBs_timed_region": stage_bytes["total"] * n_reads / (step_ms * 1e-3) / 1e9,
+               "survey_8d_GBs_resident_step": stage_bytes["total"] * n_reads / (res_ms * 1e-3) / 1e9,
+               "survey_8d_search_bytes_per_read": stage_bytes["search"],
+               "survey_8d_search_GBs": stage_bytes["search"] * n_reads / (search_ms * 1e-3) / 1e9 if search_ms > 0 else None,
+               "note": "SURVEY 8(d) bytes = what the reference's own layout must touch (64*(2X+S) + 8H + W + L + 24R); the resident k-mer table "
+                       "and full suffix array avoid most of them, so these are work rates, not fractions of the 8 TB/s roof"}
+        if prof:
+            hbm["measured_traffic_bytes_per_step"] = prof["hbm_bytes_per_step"]
+            hbm["measured_frac_of_peak_resident_step"] = prof["hbm_bytes_per_step"] / (res_ms * 1e-3) / 1e9 / PEAK_HBM_GBS
+            hbm["measured_traffic_source"] = {"file": "profiles/hbm_traffic.json", "from_profile_of_commit": prof.get("commit"), "how": prof.get("source")}
+        roof["survey_8d"] = hbm
 
     out = {
         "metric": "reads/sec (whole node), 150bp reads vs MG-index",
@@ -453,8 +502,8 @@ def main():
         "value_region": "SURVEY 8(d): wall clock over host bases in -> host hits out through the C ABI (mtsv_batch_run_host + "
                         "mtsv_batch_download = mtsv_bin_batch on a warm workspace), H2D of reads and D2H of hits included; "
                         "index load/upload excluded",
-        "timed_calls_ms_per_step": {"mtsv_batch_run_host": split[0] / args.steps * 1e3, "mtsv_batch_download": split[1] / args.steps * 1e3,
-                                    "mtsv_hits_free": split[2] / args.steps * 1e3},
+        "timed_calls_ms_per_step": {"mtsv_batch_run_host": split_timed[0] / args.steps * 1e3, "mtsv_batch_download": split_timed[1] / args.steps * 1e3,
+                                    "mtsv_hits_free": split_timed[2] / args.steps * 1e3},
         "step_ms_each": each_ms,
         "device_resident": resident,
         "host_input": "ordinary (pageable) memory" if args.pageable_input else "page-locked memory from mtsv_host_alloc",
@@ -472,7 +521,8 @@ def main():
         "overlapped_lanes": overlapped,
         "counters_per_read": ctr_per,
         "device_counters": {k: st1[k] for k in ("n_seed_slots", "n_seed_hits", "lf_steps", "n_candidates",
-                                                 "n_verified", "window_bytes", "n_hits", "n_passes", "sw_cell_pairs", "n_sw_passed")},
+                                                 "n_verified", "window_bytes", "n_hits", "n_passes", "sw_cell_pairs", "n_sw_passed",
+                                                 "n_sw_bound_refuted", "myers_columns")},
         "parity": parity,
         "other_verify_order": alt,
         "setup_s": {"index_build": t_build, "index_file_reused": index_cached, "index_load": t_load, "index_pack_upload_accel": t_upload},

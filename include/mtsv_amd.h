@@ -78,6 +78,8 @@ typedef struct {
     uint64_t sa_s;     /* suffix-array sampling interval of the file */
     uint64_t file_bytes;
     uint64_t device_bytes; /* HBM held on the device it was last uploaded to (0 if none) */
+    uint32_t kmer_k;       /* symbols of the resident k-mer interval table on that device (0: none) */
+    uint32_t sa_full;      /* 1 when the full suffix array is resident there */
 } mtsv_index_info_t;
 
 /* per-stage device time of the last mtsv_batch_run, measured with HIP events on the batch's
@@ -101,13 +103,17 @@ typedef struct {
                              * and stage_ms[7] is the wall time of the run */
     uint64_t sw_cell_pairs; /* k_sw_pairs: DP cell pairs its sweeps computed, per 16-lane group (one packed
                              * 7-instruction recurrence each; 4 groups share a wave instruction) */
-    float sw_prefilter_ms;  /* device time of the k_sw_pairs launches (HIP events on the lane's stream), summed
-                             * over lanes like stage_ms; part of stage_ms[5] */
-    float sw_sweep_ms;      /* of that, the sweeps (k_sw_pairs on the top half of the rows + at full height); the rest of
-                             * sw_prefilter_ms is k_sw_diag, the bounds on the seed diagonal */
+    float sw_prefilter_ms;  /* device time of the SW prefilter's kernels in the first round of every pass (HIP events on
+                             * the lane's stream), summed over lanes like stage_ms; part of stage_ms[5] */
+    float sw_sweep_ms;      /* of that, the DP sweeps (k_sw_pairs); the rest of sw_prefilter_ms is sw_diag_ms + sw_bound_ms */
     uint64_t n_sw_passed;   /* candidates whose SW score reached the threshold of index.rs:406, i.e. the edit
                              * distances the reference computes (:407-409).  Counted where the prefilter is a
                              * kernel of its own (reference order, reads up to 253 bases); 0 otherwise */
+    float sw_diag_ms;       /* k_sw_diag: the lower bounds on the seed diagonal */
+    float sw_bound_ms;      /* k_edit_myers in bound mode: the two-sided bound by the unit-cost edit distance */
+    float edit_ms;          /* k_edit_myers on the candidates that passed the prefilter (first round of every pass) */
+    uint64_t myers_columns; /* window columns the bit-vector recurrences of k_edit_myers advanced (bound + edit distance) */
+    uint64_t n_sw_bound_refuted; /* candidates the edit-distance bound refuted without a sweep */
 } mtsv_batch_stats;
 
 const char *mtsv_last_error(void);

@@ -29,7 +29,8 @@ class Params(C.Structure):  # mtsv_params
 
 class IndexInfo(C.Structure):  # mtsv_index_info_t
     _fields_ = [("n", C.c_uint64), ("n_bins", C.c_uint64), ("occ_k", C.c_uint32),
-                ("sa_s", C.c_uint64), ("file_bytes", C.c_uint64), ("device_bytes", C.c_uint64)]
+                ("sa_s", C.c_uint64), ("file_bytes", C.c_uint64), ("device_bytes", C.c_uint64),
+                ("kmer_k", C.c_uint32), ("sa_full", C.c_uint32)]
 
 
 N_STAGES = 8
@@ -42,7 +43,8 @@ class BatchStats(C.Structure):  # mtsv_batch_stats
                 ("n_candidates", C.c_uint64), ("n_verified", C.c_uint64),
                 ("window_bytes", C.c_uint64), ("n_hits", C.c_uint64), ("n_passes", C.c_uint64),
                 ("n_rounds", C.c_uint64), ("n_lanes", C.c_uint64), ("sw_cell_pairs", C.c_uint64), ("sw_prefilter_ms", C.c_float),
-                ("sw_sweep_ms", C.c_float), ("n_sw_passed", C.c_uint64)]
+                ("sw_sweep_ms", C.c_float), ("n_sw_passed", C.c_uint64), ("sw_diag_ms", C.c_float), ("sw_bound_ms", C.c_float),
+                ("edit_ms", C.c_float), ("myers_columns", C.c_uint64), ("n_sw_bound_refuted", C.c_uint64)]
 
     def as_dict(self):
         d = {n: (float(getattr(self, n)) if t is C.c_float else int(getattr(self, n))) for n, t in self._fields_[1:]}

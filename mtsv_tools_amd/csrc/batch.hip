@@ -135,7 +135,9 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_counters, kCounters, &bytes);
     alloc_hit_workspace();
     dev_alloc(&d_hits, hits_cap, &bytes);
-    HIP_CHECK(hipHostMalloc((void**)&h_counters, kCounters * sizeof(uint64_t)));
+    // page-locked and mapped: kernels store the counters the host waits for straight into it (launch_publish) -- a
+    // hipMemcpyAsync of 8 bytes can queue on a copy engine behind tens of milliseconds of the reads' own transfer
+    HIP_CHECK(hipHostMalloc((void**)&h_counters, kCounters * sizeof(uint64_t), hipHostMallocMapped));
     if (const char* e = getenv("MTSV_SW")) sw_pairs = strcmp(e, "packed") != 0;
     if (const char* e = getenv("MTSV_SW_DIAG")) sw_diag = atoi(e) != 0;
     if (const char* e = getenv("MTSV_SW_PREPASS")) sw_prepass = atoi(e) != 0;
@@ -164,14 +166,18 @@ Batch::~Batch() {
     (void)hipFree(d_strip);
     if (h_hits_stage) pinned_hits_release(h_hits_stage);
     if (copy_stream2) (void)hipStreamDestroy(copy_stream2);
-    for (auto& rb : ring) {
-        (void)hipFree(rb.d_bases);
-        (void)hipFree(rb.d_off);
-        if (rb.h_bases) (void)hipHostFree(rb.h_bases);
-        if (rb.h_off) (void)hipHostFree(rb.h_off);
+    if (copy_stream) {
+        (void)hipStreamSynchronize(copy_stream);
+        (void)hipStreamDestroy(copy_stream);
     }
-    for (auto& cs : copy_streams)
-        if (cs) (void)hipStreamDestroy(cs);
+    for (auto& ar : arena) {
+        (void)hipFree(ar.d_bases);
+        (void)hipFree(ar.d_off);
+    }
+    if (h_off_all) (void)hipHostFree(h_off_all);
+    for (auto& hs : h_stage)
+        if (hs) (void)hipHostFree(hs);
+    for (auto& e : chunk_ev) (void)hipEventDestroy(e);
     (void)hipHostFree(h_counters);
     for (auto& e : ev) (void)hipEventDestroy(e);
     (void)hipStreamDestroy(stream);
@@ -234,7 +240,7 @@ void Batch::reset_lane() {
     memset(&stats, 0, sizeof stats);
     memset(stage_acc, 0, sizeof stage_acc);
     sw_ms_acc = 0;
-    sweep_ms_acc = 0;
+    sweep_ms_acc = diag_ms_acc = bound_ms_acc = edit_ms_acc = 0;
     sw_passed_acc = 0;
     n_hits_total = 0;
     HIP_CHECK(hipMemsetAsync(d_counters, 0, kCounters * sizeof(uint64_t), stream));
@@ -243,12 +249,17 @@ void Batch::reset_lane() {
 
 void Batch::finish_lane() {
     HIP_CHECK(hipEventRecord(ev[9], stream));
-    HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, kCounters * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+    launch_publish(stream, d_counters, h_counters, kCounters);
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipEventElapsedTime(&stage_acc[7], ev[8], ev[9]));
     stats.sw_cell_pairs = h_counters[14];
     stats.sw_prefilter_ms = sw_ms_acc;
     stats.sw_sweep_ms = sweep_ms_acc;
+    stats.sw_diag_ms = diag_ms_acc;
+    stats.sw_bound_ms = bound_ms_acc;
+    stats.edit_ms = edit_ms_acc;
+    stats.myers_columns = h_counters[19];
+    stats.n_sw_bound_refuted = h_counters[20];
     stats.n_sw_passed = sw_passed_acc;
     stats.lf_steps = h_counters[2];
     stats.n_candidates = h_counters[3];
@@ -299,6 +310,11 @@ void Batch::end_run() {
         stats.sw_cell_pairs += l->stats.sw_cell_pairs;
         stats.sw_prefilter_ms += l->stats.sw_prefilter_ms;
         stats.sw_sweep_ms += l->stats.sw_sweep_ms;
+        stats.sw_diag_ms += l->stats.sw_diag_ms;
+        stats.sw_bound_ms += l->stats.sw_bound_ms;
+        stats.edit_ms += l->stats.edit_ms;
+        stats.myers_columns += l->stats.myers_columns;
+        stats.n_sw_bound_refuted += l->stats.n_sw_bound_refuted;
         stats.n_sw_passed += l->stats.n_sw_passed;
     }
     if (overlapped) stage_acc[7] = (float)wall_ms;
@@ -333,6 +349,10 @@ void Batch::run_range(const mtsv_params& p, const uint8_t* raw, uint8_t* sb, con
     uint64_t n_chunks = std::max<uint64_t>(k, (n + ws_reads - 1) / ws_reads);
     if (k > 1 && n >= k * per_lane * kLaneMinReads) n_chunks = std::max(n_chunks, k * per_lane);
     std::vector<uint64_t> bound(n_chunks + 1, n);
+    bound[0] = 0;
+    // (the short first chunks make the full ones longer: more chunks until a full one fits the workspace)
+    while (k > 1 && n_chunks >= 2 * k && (double)n / ((double)n_chunks - (double)(k - 1) / 2.0) > (double)ws_reads) n_chunks++;
+    bound.assign(n_chunks + 1, n);
     bound[0] = 0;
     if (k > 1 && n_chunks >= 2 * k) {
         // sizes: per * 1/k, per * 2/k, .., per, then equal chunks of the rest
@@ -461,7 +481,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
             HIP_CHECK(hipMemsetAsync(d_strand_nseeds, 0, (uint64_t)nstr * 4, stream));
         }
         launch_scan(stream, d_strand_hits, nstr, d_tile_sums, d_counters + 0, d_strand_off);
-        HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, 8, hipMemcpyDeviceToHost, stream));
+        launch_publish(stream, d_counters, h_counters, 1);
         HIP_CHECK(hipEventRecord(ev[2], stream));
         HIP_CHECK(hipStreamSynchronize(stream));
         const uint64_t total_hits = h_counters[0];
@@ -520,7 +540,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                 // strips sized from the longest window of the pass (one small round trip; long reads are rare)
                 HIP_CHECK(hipMemsetAsync(d_counters + 13, 0, sizeof(uint64_t), stream));
                 launch_max_window(stream, nstr, d_strand_off, d_strand_ncand, d_cand, (unsigned long long*)(d_counters + 13));
-                HIP_CHECK(hipMemcpyAsync(h_counters + 13, d_counters + 13, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+                launch_publish(stream, d_counters + 13, h_counters + 13, 1);
                 HIP_CHECK(hipStreamSynchronize(stream));
                 const uint32_t strip_len = (uint32_t)std::max<uint64_t>(h_counters[13], 1);
                 const uint64_t need = (uint64_t)tiled_groups(total_hits, strip_len) * strip_len;
@@ -588,7 +608,9 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                         bd.wl_cursor = (uint32_t*)(d_counters + 18);
                         bd.und_list = (uint32_t*)d_hit_row;
                         bd.und_slot = 17;
+                        bd.myers_ctr = (unsigned long long*)(d_counters + 19);
                         launch_edit_myers(stream, v, bd, items, pass_max_len, 2);
+                        HIP_CHECK(hipEventRecord(ev[13], stream));
                         sw.worklist = bd.und_list;
                         sw.wl_count_slot = 17;
                         sw.wl_reverse = 0;
@@ -625,17 +647,32 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                     my.wl_cursor = (uint32_t*)(d_counters + 10);
                     my.next_list = next_lists[round & 1];
                     my.next_count = (uint32_t*)next_slot;
+                    my.myers_ctr = (unsigned long long*)(d_counters + 19);
                     launch_edit_myers(stream, v, my, items, pass_max_len, 1);
-                    HIP_CHECK(hipMemcpyAsync(h_counters + 11, next_slot, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipMemcpyAsync(h_counters + 9, d_counters + 9, sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+                    if (round == 0) HIP_CHECK(hipEventRecord(ev[14], stream));
+                    launch_publish(stream, next_slot, h_counters + 11, 1);
+                    launch_publish(stream, d_counters + 9, h_counters + 9, 1);
                     HIP_CHECK(hipStreamSynchronize(stream));
                     sw_passed_acc += h_counters[9] & 0xffffffffull;
                     if (round == 0) {
                         float ms = 0;
                         HIP_CHECK(hipEventElapsedTime(&ms, ev[10], ev[11]));
                         sw_ms_acc += ms;
-                        if (sw_diag && sw_prepass) HIP_CHECK(hipEventElapsedTime(&ms, ev[12], ev[11]));
+                        int from = 10;  // the sweeps start after whichever bound kernels ran
+                        if (sw_diag && sw_prepass) {
+                            HIP_CHECK(hipEventElapsedTime(&ms, ev[10], ev[12]));
+                            diag_ms_acc += ms;
+                            from = 12;
+                        }
+                        if (sw_bound) {
+                            HIP_CHECK(hipEventElapsedTime(&ms, ev[from], ev[13]));
+                            bound_ms_acc += ms;
+                            from = 13;
+                        }
+                        HIP_CHECK(hipEventElapsedTime(&ms, ev[from], ev[11]));
                         sweep_ms_acc += ms;
+                        HIP_CHECK(hipEventElapsedTime(&ms, ev[11], ev[14]));
+                        edit_ms_acc += ms;
                     }
                     const uint64_t n_next = h_counters[11] & 0xffffffffull;
                     if (n_next == 0) break;
@@ -653,7 +690,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         HIP_CHECK(hipEventRecord(ev[6], stream));
         // ---- gather ----
         launch_scan(stream, d_strand_nout, nstr, d_tile_sums, d_counters + 6, d_out_off);
-        HIP_CHECK(hipMemcpyAsync(h_counters, d_counters, 8 * sizeof(uint64_t), hipMemcpyDeviceToHost, stream));
+        launch_publish(stream, d_counters, h_counters, 8);
         HIP_CHECK(hipStreamSynchronize(stream));
         const uint64_t total_out = h_counters[6];
         if (n_hits_total + total_out > hits_cap) {
@@ -757,54 +794,102 @@ mtsv_hit* pinned_hits_alloc(uint64_t n_hits, uint64_t* cap_hits) {
 }
 bool pinned_hits_release(void* p) { return p && pool().put(p); }
 
-// Host buffers in, hits in pinned host memory out.  The reads are cut into slices of at most one lane's
-// workspace; `uploaders` threads stage slice k through pinned memory into ring buffer k % NB (host memcpy,
-// DMA on the thread's copy stream, base normalisation there too) while the lanes -- one host thread and
-// stream each -- pull ready slices in order and run the pipeline on them.  A finished slice's hits start
-// their way to the pinned result array at once, in slice order, on a third stream.  Nothing waits for a
-// whole batch: the steady state runs at max(kernels, staging, DMA).
+// Host buffers in, hits in pinned host memory out.
+//
+// The PCIe rate of the reads (~50 GB/s = 330 k reads of 150 bases per ms) and the rate of the kernels are about
+// equal, so the copy must run flat out from the first microsecond and the kernels must follow right behind it:
+//   * one FEEDER thread copies the batch, strictly in read order, in chunks of a few MB (growing to 32 MB) on one
+//     copy stream into an ARENA in HBM that holds the whole batch (or 3 GiB segments of it, two arenas taking
+//     turns), an event after every chunk.  Bases in page-locked memory are copied from where they lie, others are
+//     staged through a few page-locked chunk buffers; the u64 offsets are narrowed to arena-relative u32 on the way;
+//   * the LANES -- a host thread and a stream each -- take the reads that HAVE ARRIVED and nobody has taken yet:
+//     a pass is a range of reads of the arena, as large as the ramp allows and the copy has delivered, never
+//     tied to how the copy was cut.  An idle device takes what is there; while other lanes keep it busy a lane
+//     waits for a worthwhile range (the ramp grows with the reads already taken and falls towards the end, so
+//     the lanes finish together);
+//   * a finished range's hits leave for the pinned result array at once, in read order, on a third stream.
+// ---------------------------------------------------------------------------------------------
 void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p, uint64_t read_base) {
     const double t_entry = now_s();
     HIP_CHECK(hipSetDevice(di->device));
     std::vector<Batch*> ls{this};
     for (auto& l : extra) ls.push_back(l.get());
-    const size_t NB = ls.size() + 2;
-    const uint64_t slice_reads = ws_reads;
-    const uint64_t slice_bases = std::max<uint64_t>(max_bases / ls.size() + 4096, 1 << 16);
-    if (ring.size() != NB) {
-        ring.resize(NB);
-        for (auto& rb : ring) {
-            dev_alloc(&rb.d_bases, slice_bases + 64, &bytes);
-            dev_alloc(&rb.d_off, slice_reads + 1, &bytes);
-            HIP_CHECK(hipHostMalloc((void**)&rb.h_bases, slice_bases + 64));
-            HIP_CHECK(hipHostMalloc((void**)&rb.h_off, (slice_reads + 1) * sizeof(uint32_t)));
-        }
-        for (auto& cs : copy_streams) HIP_CHECK(hipStreamCreateWithFlags(&cs, hipStreamNonBlocking));
-        HIP_CHECK(hipStreamCreateWithFlags(&copy_stream2, hipStreamNonBlocking));
-    }
     const bool trace = getenv("MTSV_TRACE") != nullptr;
+    if (!copy_stream) {
+        // The copy streams get a priority of their own.  The runtime maps streams onto a few hardware queues (four by
+        // default, GPU_MAX_HW_QUEUES) round robin, per priority; an asynchronous copy holds its queue with a barrier
+        // packet until the copy engine is done, and with it every kernel of any stream that shares the queue -- a lane
+        // that shared one with the reads' transfer did not get a kernel in for 20 ms at a time.
+        int prio_low = 0, prio_high = 0;
+        HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_low, &prio_high));
+        HIP_CHECK(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_high));
+        HIP_CHECK(hipStreamCreateWithPriority(&copy_stream2, hipStreamNonBlocking, prio_high));
+    }
+    if (n && read_off[n] < read_off[0]) throw std::runtime_error("arg: read_off is not ascending");
+    const uint64_t first_base = n ? read_off[0] : 0, total_bases = n ? read_off[n] - first_base : 0;
     // bases in page-locked memory (mtsv_host_alloc / mtsv_host_register) go to the GPU from where they lie
-    const bool direct = n && host_pinned(bases, read_off[n]) && !getenv("MTSV_STAGE_ALWAYS");
+    const bool direct = n && total_bases && host_pinned(bases + first_base, total_bases) && !getenv("MTSV_STAGE_ALWAYS");
     if (trace) fprintf(stderr, "[run_host] input %s\n", direct ? "page-locked: copied from the caller's buffer" : "pageable: staged");
-    struct Slice {
+
+    // ---- arenas: segments of at most kArenaBases bases / kArenaReads reads (u32 offsets inside a segment) ----
+    uint64_t arena_bases = kArenaBases, arena_reads = kArenaReads;
+    if (const char* e = getenv("MTSV_ARENA_BASES")) arena_bases = std::max<uint64_t>(1 << 16, strtoull(e, nullptr, 10));  // (tests)
+    const bool one_segment = total_bases <= arena_bases && n <= arena_reads;
+    {
+        const uint64_t want_b = one_segment ? total_bases : arena_bases, want_r = one_segment ? n : std::min(n, arena_reads);
+        for (int k = 0; k < (one_segment ? 1 : 2); k++) {
+            Arena& ar = arena[k];
+            if (ar.cap_bases < want_b || ar.cap_reads < want_r) {
+                if (trace) fprintf(stderr, "[run_host] arena %d: %.1f MB of bases, %llu reads\n", k, want_b / 1e6, (unsigned long long)want_r);
+                (void)hipFree(ar.d_bases);
+                (void)hipFree(ar.d_off);
+                ar.d_bases = nullptr;
+                ar.d_off = nullptr;
+                ar.cap_bases = ar.cap_reads = 0;
+                const uint64_t cb = want_b + want_b / 16, cr = want_r + want_r / 16;  // a little room: the next batch is rarely the same size
+                dev_alloc(&ar.d_bases, std::min(cb, arena_bases) + 64, &bytes);  // k_search reads up to 36 bytes past a seed start
+                dev_alloc(&ar.d_off, std::min(cr, arena_reads) + 1, &bytes);
+                ar.cap_bases = std::min(cb, arena_bases);
+                ar.cap_reads = std::min(cr, arena_reads);
+            }
+        }
+    }
+    // the whole batch's narrowed offsets, every segment with a closing entry of its own (a segment is closed when the next
+    // read does not fit: it is more than half full); run_slice looks at read lengths on the host when a range holds long reads
+    const uint64_t off_need = n + 2 + (one_segment ? 0 : 2 * (total_bases / arena_bases + n / arena_reads) + 8);
+    if (h_off_cap < off_need) {
+        if (h_off_all) (void)hipHostFree(h_off_all);
+        h_off_all = nullptr;
+        h_off_cap = off_need + n / 16;
+        HIP_CHECK(hipHostMalloc((void**)&h_off_all, h_off_cap * sizeof(uint32_t)));
+    }
+    constexpr uint64_t kChunkMax = 32ull << 20, kChunkMin = 4ull << 20;
+    if (!direct && !h_stage[0])
+        for (auto& hs : h_stage) HIP_CHECK(hipHostMalloc((void**)&hs, kChunkMax + 64));
+
+    struct Chunk {
+        uint64_t begin = 0, end = 0;  // reads
+        uint32_t max_len = 0, seg = 0;
+        hipEvent_t ev = nullptr;
+        bool complete = false;
+    };
+    struct Range {
         uint64_t begin = 0, end = 0;
-        uint32_t max_len = 0;
-        bool ready = false, done = false;
-        size_t buf = 0;
+        bool done = false;
         Batch* lane = nullptr;
         uint64_t hit_off = 0, hit_cnt = 0;
     };
-    std::mutex mu;  // slices, cursors, commit state
+    std::mutex mu;  // chunks, ranges, cursors, commit state
     std::condition_variable cv;
-    std::vector<Slice> slices;
-    uint64_t cut_at = 0;       // reads already cut into slices
-    uint64_t next_grant = 0;   // next slice to be given an input buffer
-    std::vector<size_t> free_bufs;
-    for (size_t b = 0; b < NB; b++) free_bufs.push_back(b);
-    uint64_t ramp_floor = 256 << 10;  // measured on config2: 96 Ki .. 320 Ki within 1 %, 512 Ki 3 % slower, 1 Mi 15 % slower
-    if (const char* e = getenv("MTSV_RAMP_FLOOR")) ramp_floor = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));
-    uint64_t next_take = 0;    // next slice a lane takes
-    uint64_t next_commit = 0;  // next slice whose hits go to the host
+    std::vector<Chunk> chunks;            // issued copies, in read order
+    std::vector<uint64_t> seg_begin{0};   // first read of every segment (feeder appends)
+    uint64_t n_complete = 0;              // chunks [0, n_complete) have arrived
+    bool issued_all = n == 0;
+    std::vector<Range> ranges;
+    uint64_t next_read = 0;    // first read no lane has taken
+    uint64_t next_commit = 0;  // next range whose hits go to the host
+    uint64_t done_prefix = 0;  // reads [0, done_prefix) are through the kernels (arena reuse)
+    int busy_lanes = 0;
     bool abort = false;
     std::exception_ptr first_err;
     auto fail = [&](std::exception_ptr e) {
@@ -812,6 +897,14 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
         if (!first_err) first_err = e;
         abort = true;
         cv.notify_all();
+    };
+    auto event_for = [&](size_t k) {
+        while (chunk_ev.size() <= k) {
+            hipEvent_t e;
+            HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+            chunk_ev.push_back(e);
+        }
+        return chunk_ev[k];
     };
 
     n_reads = n;
@@ -826,79 +919,152 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
         h_hits_stage = pinned_hits_alloc(last_total_hits ? last_total_hits + last_total_hits / 64 : n + n / 8, &h_hits_cap);
     }
     if (trace) fprintf(stderr, "[run_host] result array of %llu hits ready at %.2f ms\n", (unsigned long long)h_hits_cap, (now_s() - t_entry) * 1e3);
+    const uint64_t n_lanes_used = n >= ls.size() * kLaneMinReads ? ls.size() : 1;
+    lanes_used = n_lanes_used;
 
-    // ---- uploaders ----
-    auto uploader = [&](int tid) {
+    // ---- feeder ----
+    // Only the WATCHER thread looks at the copies' events, by polling, and publishes what has arrived (lanes that
+    // blocked in hipEventSynchronize while a third lane sat in hipStreamSynchronize kept that lane from returning
+    // for 10 ms at a time).
+    auto watcher = [&]() {
         try {
             HIP_CHECK(hipSetDevice(di->device));
-            hipStream_t cs = copy_streams[tid];
+            size_t c = 0;
             for (;;) {
-                uint64_t k, s, e;
-                size_t bi;
-                {
-                    std::unique_lock<std::mutex> lk(mu);
-                    if (abort || cut_at >= n) return;
-                    // cut the next slice: a short first one so the kernels start early, then full ones
-                    s = cut_at;
-                    k = slices.size();
-                    // Slice sizes ramp up from small ones (every lane has work after the first millisecond of
-                    // copying) and taper off towards the end of the batch (the lanes finish together).
-                    uint64_t want = slice_reads;
-                    if (n > 2 * slice_reads) {
-                        const uint64_t lanes = ls.size(), floor_reads = std::min<uint64_t>(slice_reads, ramp_floor);
-                        const uint64_t up = floor_reads + s / lanes;                  // grows with the reads already cut
-                        const uint64_t down = std::max(floor_reads, (n - s) / (lanes + 1));  // shrinks with the reads left
-                        want = std::min(slice_reads, std::min(up, down));
-                    }
-                    e = std::min(n, s + want);
-                    if (read_off[e] < read_off[s]) throw std::runtime_error("arg: read_off is not ascending");
-                    if (read_off[e] - read_off[s] > slice_bases) {  // largest e with at most slice_bases bases
-                        uint64_t lo = s, hi = e;
-                        while (lo < hi) {
-                            uint64_t mid = (lo + hi + 1) / 2;
-                            if (read_off[mid] >= read_off[s] && read_off[mid] - read_off[s] <= slice_bases) lo = mid;
-                            else hi = mid - 1;
-                        }
-                        e = lo;
-                        if (e == s) throw std::runtime_error("limit: one read holds more bases than the batch workspace");
-                    }
-                    slices.emplace_back();
-                    slices[k].begin = s;
-                    slices[k].end = e;
-                    cut_at = e;
-                    // input buffers are granted in slice order (a later slice must not starve an earlier one the
-                    // lanes are waiting for) and come back in any order
-                    cv.wait(lk, [&] { return abort || (k == next_grant && !free_bufs.empty()); });
-                    if (abort) return;
-                    slices[k].buf = free_bufs.back();
-                    free_bufs.pop_back();
-                    next_grant++;
-                    bi = slices[k].buf;
-                }
-                cv.notify_all();
-                RingBuf& rb = ring[bi];
-                const uint64_t cnt = e - s, first = read_off[s], nb = read_off[e] - first;
-                uint32_t ml = 0;
-                for (uint64_t i = 0; i <= cnt; i++) {
-                    if (i && read_off[s + i] < read_off[s + i - 1]) throw std::runtime_error("arg: read_off is not ascending");
-                    rb.h_off[i] = (uint32_t)(read_off[s + i] - first);
-                    if (i) ml = std::max(ml, rb.h_off[i] - rb.h_off[i - 1]);
-                }
-                const double t0 = now_s();
-                if (nb) {
-                    if (!direct) parallel_copy(rb.h_bases, bases + first, nb);
-                    HIP_CHECK(hipMemcpyAsync(rb.d_bases, direct ? bases + first : rb.h_bases, nb, hipMemcpyHostToDevice, cs));
-                }
-                HIP_CHECK(hipMemcpyAsync(rb.d_off, rb.h_off, (cnt + 1) * 4, hipMemcpyHostToDevice, cs));
-                const double t1 = now_s();
-                HIP_CHECK(hipStreamSynchronize(cs));
-                if (trace) fprintf(stderr, "[run_host] slice %llu (%llu reads): stage %.1f ms, h2d %.1f ms (%.1f MB) at %.1f ms\n", (unsigned long long)k, (unsigned long long)cnt, (t1 - t0) * 1e3, (now_s() - t1) * 1e3, nb / 1e6, (now_s() - run_t0) * 1e3);
+                size_t upto;
+                bool last;
+                std::vector<hipEvent_t> evs;
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    slices[k].max_len = ml;
-                    slices[k].ready = true;
+                    if (abort) return;
+                    upto = chunks.size();
+                    last = issued_all;
+                    for (size_t i = c; i < upto; i++) evs.push_back(chunks[i].ev);
+                }
+                const size_t c0 = c;
+                while (c < upto) {
+                    const hipError_t q = hipEventQuery(evs[c - c0]);
+                    if (q == hipSuccess) c++;
+                    else if (q == hipErrorNotReady) break;
+                    else throw_hip(q, "hipEventQuery(chunk)", __FILE__, __LINE__);
+                }
+                if (c != c0) {
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        n_complete = c;
+                    }
+                    cv.notify_all();
+                }
+                if (last && c == upto) return;
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+        } catch (...) {
+            fail(std::current_exception());
+        }
+    };
+    auto feeder = [&]() {
+        try {
+            HIP_CHECK(hipSetDevice(di->device));
+            uint64_t r = 0, seg = 0, seg_first_base = first_base, seg_first_read = 0;
+            uint64_t chunk_bytes = kChunkMin;
+            size_t k = 0;
+            while (r < n) {
+                // the chunk: whole reads, about chunk_bytes of bases, inside the current segment
+                uint64_t e = r;
+                {
+                    // largest e with read_off[e] - read_off[r] <= chunk_bytes (at least one read)
+                    uint64_t lo = r + 1, hi = n;
+                    const uint64_t lim = read_off[r] + chunk_bytes;
+                    if (read_off[hi] > lim) {
+                        while (lo < hi) {
+                            const uint64_t mid = (lo + hi + 1) / 2;
+                            if (read_off[mid] <= lim) lo = mid;
+                            else hi = mid - 1;
+                        }
+                        hi = lo;
+                    }
+                    e = hi;
+                }
+                Arena* ar = &arena[seg & 1];
+                if (read_off[e] - seg_first_base > ar->cap_bases || e - seg_first_read > ar->cap_reads) {
+                    // does not fit the segment any more: shorten to what fits, or open the next segment
+                    uint64_t lo = r, hi = e;
+                    while (lo < hi) {
+                        const uint64_t mid = (lo + hi + 1) / 2;
+                        if (read_off[mid] - seg_first_base <= ar->cap_bases && mid - seg_first_read <= ar->cap_reads) lo = mid;
+                        else hi = mid - 1;
+                    }
+                    if (lo == r) {
+                        if (r == seg_first_read) throw std::runtime_error("limit: one read holds more bases than an input segment (" + std::to_string(ar->cap_bases) + ")");
+                        seg++;
+                        seg_first_base = read_off[r];
+                        seg_first_read = r;
+                        ar = &arena[seg & 1];
+                        {
+                            std::lock_guard<std::mutex> lk(mu);
+                            seg_begin.push_back(r);
+                        }
+                        cv.notify_all();  // lanes waiting for more reads of the closed segment take what it has
+                        if (seg >= 2) {  // the arena's previous tenant (segment seg - 2) must be through the kernels
+                            std::unique_lock<std::mutex> lk(mu);
+                            cv.wait(lk, [&] { return abort || done_prefix >= seg_begin[seg - 1]; });
+                            if (abort) return;
+                        }
+                        continue;  // cut the chunk again inside the new segment
+                    }
+                    e = lo;
+                }
+                const uint64_t cnt = e - r, b0 = read_off[r], nb = read_off[e] - b0;
+                const uint64_t dst_b = b0 - seg_first_base, dst_r = r - seg_first_read;
+                // offsets relative to the segment's first base; h_off_all[seg ... ] holds them at index (read + seg) so that
+                // every segment has its own closing entry
+                uint32_t* ho = h_off_all + r + seg;
+                if (r + seg + cnt + 1 > h_off_cap) throw std::runtime_error("internal: more input segments than the offset array was sized for");
+                uint32_t ml = 0;
+                if (r == seg_first_read) ho[0] = 0;  // (else the previous chunk wrote this entry; a lane may be reading it)
+                for (uint64_t i = 1; i <= cnt; i++) {
+                    if (read_off[r + i] < read_off[r + i - 1]) throw std::runtime_error("arg: read_off is not ascending");
+                    const uint32_t v = (uint32_t)(read_off[r + i] - seg_first_base);
+                    ml = std::max(ml, v - ho[i - 1]);
+                    ho[i] = v;
+                }
+                const double t0 = now_s();
+                hipEvent_t ev = event_for(k);
+                if (nb) {
+                    const uint8_t* src = bases + b0;
+                    if (!direct) {
+                        uint8_t* hs = h_stage[k % kStage];
+                        if (k >= kStage) {  // its last copy must have left (polled, like the watcher)
+                            for (;;) {
+                                const hipError_t q = hipEventQuery(chunk_ev[k - kStage]);
+                                if (q == hipSuccess) break;
+                                if (q != hipErrorNotReady) throw_hip(q, "hipEventQuery(stage)", __FILE__, __LINE__);
+                                std::this_thread::sleep_for(std::chrono::microseconds(20));
+                            }
+                        }
+                        parallel_copy(hs, src, nb);
+                        src = hs;
+                    }
+                    HIP_CHECK(hipMemcpyAsync(ar->d_bases + dst_b, src, nb, hipMemcpyHostToDevice, copy_stream));
+                }
+                HIP_CHECK(hipMemcpyAsync(ar->d_off + dst_r, ho, (cnt + 1) * 4, hipMemcpyHostToDevice, copy_stream));
+                HIP_CHECK(hipEventRecord(ev, copy_stream));
+                if (trace) fprintf(stderr, "[run_host] chunk %zu: reads %llu..%llu (%.1f MB, segment %llu) issued at %.2f ms (host side %.2f ms)\n", k, (unsigned long long)r, (unsigned long long)e, nb / 1e6, (unsigned long long)seg, (now_s() - run_t0) * 1e3, (now_s() - t0) * 1e3);
+                {
+                    std::lock_guard<std::mutex> lk(mu);
+                    Chunk c;
+                    c.begin = r;
+                    c.end = e;
+                    c.max_len = ml;
+                    c.seg = (uint32_t)seg;
+                    c.ev = ev;
+                    chunks.push_back(c);
+                    if (e == n) issued_all = true;
                 }
                 cv.notify_all();
+                r = e;
+                k++;
+                chunk_bytes = std::min(kChunkMax, chunk_bytes * 2);
             }
         } catch (...) {
             fail(std::current_exception());
@@ -906,26 +1072,32 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     };
 
     // ---- lanes ----
-    auto commit_ready = [&]() {  // mu held: hits of finished slices leave for the host in slice order
-        while (next_commit < slices.size() && slices[next_commit].done) {
-            Slice& sl = slices[next_commit];
-            if (sl.hit_cnt) {
-                stage_reserve(staged_hits + sl.hit_cnt);
-                HIP_CHECK(hipMemcpyAsync(h_hits_stage + staged_hits, sl.lane->d_hits + sl.hit_off, sl.hit_cnt * sizeof(mtsv_hit),
+    auto commit_ready = [&]() {  // mu held: hits of finished ranges leave for the host in read order
+        while (next_commit < ranges.size() && ranges[next_commit].done) {
+            Range& rg = ranges[next_commit];
+            if (rg.hit_cnt) {
+                stage_reserve(staged_hits + rg.hit_cnt);
+                HIP_CHECK(hipMemcpyAsync(h_hits_stage + staged_hits, rg.lane->d_hits + rg.hit_off, rg.hit_cnt * sizeof(mtsv_hit),
                                          hipMemcpyDeviceToHost, copy_stream2));
-                staged_hits += sl.hit_cnt;
+                staged_hits += rg.hit_cnt;
             }
-            segments.push_back(Segment{sl.lane, sl.hit_off, sl.hit_cnt});
+            segments.push_back(Segment{rg.lane, rg.hit_off, rg.hit_cnt});
+            done_prefix = rg.end;
             next_commit++;
         }
     };
+    uint64_t ramp_floor = 256 << 10;
+    if (const char* e = getenv("MTSV_RAMP_FLOOR")) ramp_floor = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));
+    const bool greedy = getenv("MTSV_TAKE_GREEDY") != nullptr;
+    uint64_t idle_take = 64 << 10;  // an idle device starts on this little
+    if (const char* e = getenv("MTSV_IDLE_TAKE")) idle_take = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
     auto lane_main = [&](Batch* lane) {
         try {
             HIP_CHECK(hipSetDevice(di->device));
-            uint64_t last_done = ~0ull;  // the last slice this lane finished
+            uint64_t last_done = ~0ull;  // the last range this lane finished
             for (;;) {
-                uint64_t k;
-                Slice sl;
+                uint64_t k = 0, rb = 0, re = 0, seg_first = 0;
+                uint32_t seg = 0, ml = 0;
                 {
                     std::unique_lock<std::mutex> lk(mu);
                     // The lane's result array only has to hold hits until they have left for the host: once it is half
@@ -935,31 +1107,76 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                         HIP_CHECK(hipStreamSynchronize(copy_stream2));
                         lane->n_hits_total = 0;
                     }
-                    cv.wait(lk, [&] {
-                        return abort || (next_take < slices.size() && slices[next_take].ready) || (cut_at >= n && next_take >= slices.size());
-                    });
-                    if (abort || next_take >= slices.size()) return;  // failed elsewhere / every slice taken
-                    k = next_take++;
-                    sl = slices[k];
+                    for (;;) {
+                        if (abort || next_read >= n) return;  // failed elsewhere / every read taken
+                        const uint64_t arrived = n_complete ? chunks[n_complete - 1].end : 0;
+                        const bool all_arrived = issued_all && n_complete == chunks.size();
+                        // the segment next_read lies in: a range stays inside one
+                        size_t sg = seg_begin.size() - 1;
+                        while (seg_begin[sg] > next_read) sg--;
+                        const uint64_t seg_end = sg + 1 < seg_begin.size() ? seg_begin[sg + 1] : n;
+                        const uint64_t avail = std::min(arrived, seg_end) > next_read ? std::min(arrived, seg_end) - next_read : 0;
+                        // the ramp: grows with the reads already taken, falls with the reads left
+                        uint64_t want = ws_reads;
+                        if (n > 2 * ws_reads) {
+                            const uint64_t floor_reads = std::min<uint64_t>(ws_reads, ramp_floor);
+                            const uint64_t up = floor_reads + next_read / n_lanes_used;
+                            const uint64_t down = std::max(floor_reads, (n - next_read) / (n_lanes_used + 1));
+                            want = std::min(ws_reads, std::min(up, down));
+                        }
+                        uint64_t take = 0;
+                        if (greedy) {
+                            // everything that has arrived, once it is worth a pass; the last reads in equal parts
+                            const uint64_t floor_reads = std::min<uint64_t>(ws_reads, ramp_floor);
+                            const uint64_t left = n - next_read;
+                            if (all_arrived || arrived >= seg_end) {
+                                const uint64_t parts = std::max<uint64_t>(1, std::min<uint64_t>(n_lanes_used, (avail + floor_reads - 1) / floor_reads));
+                                take = std::min(ws_reads, (avail + parts - 1) / parts);
+                            } else if (avail >= std::min(floor_reads, left)) take = std::min(ws_reads, avail);
+                            else if (busy_lanes == 0 && avail >= std::min(idle_take, left)) take = avail;
+                        } else {
+                        if (avail >= want) take = want;
+                        else if (avail && (all_arrived || arrived >= seg_end)) take = avail;            // nothing more will come for it
+                        else if (busy_lanes == 0 && avail >= std::min(idle_take, want)) take = avail;  // do not leave the device idle
+                        }
+                        if (take) {
+                            rb = next_read;
+                            re = next_read + take;
+                            next_read = re;
+                            seg = (uint32_t)sg;
+                            seg_first = seg_begin[sg];
+                            for (size_t c = 0; c < n_complete; c++)  // (a few dozen chunks)
+                                if (chunks[c].end > rb && chunks[c].begin < re) ml = std::max(ml, chunks[c].max_len);
+                            k = ranges.size();
+                            ranges.emplace_back();
+                            ranges[k].begin = rb;
+                            ranges[k].end = re;
+                            busy_lanes++;
+                            break;
+                        }
+                        cv.wait(lk);  // for the next copy to arrive (the feeder watches them), or for a lane to finish (the idle rule)
+                    }
                 }
                 cv.notify_all();
-                const RingBuf& rb = ring[sl.buf];
+                const Arena& ar = arena[seg & 1];
+                const uint32_t* ho = h_off_all + rb + seg;  // offsets of reads rb .. re inside segment seg
+                const uint32_t* dso = ar.d_off + (rb - seg_first);
                 const uint64_t before = lane->n_hits_total;
                 const double t0 = now_s();
                 // base normalisation (binner.rs:88-100) in place, on the lane's own stream: a kernel on the copy
                 // stream would queue behind the persistent verification kernels of the other lanes
-                launch_normalise(lane->stream, rb.d_bases, rb.d_bases, 0, rb.h_off[sl.end - sl.begin]);
-                lane->run_slice(p, rb.d_bases, rb.d_off, rb.h_off, sl.end - sl.begin, sl.max_len, read_base + sl.begin);
-                if (trace) fprintf(stderr, "[run_host] slice %llu: kernels %.1f ms, done at %.1f ms\n", (unsigned long long)k, (now_s() - t0) * 1e3, (now_s() - run_t0) * 1e3);
+                launch_normalise(lane->stream, ar.d_bases, ar.d_bases, ho[0], ho[re - rb]);
+                lane->run_slice(p, ar.d_bases, dso, ho, re - rb, ml, read_base + rb);
+                if (trace) fprintf(stderr, "[run_host] range %llu (reads %llu..%llu): kernels %.1f ms, done at %.1f ms\n", (unsigned long long)k, (unsigned long long)rb, (unsigned long long)re, (now_s() - t0) * 1e3, (now_s() - run_t0) * 1e3);
                 {
                     std::lock_guard<std::mutex> lk(mu);
-                    slices[k].lane = lane;
-                    slices[k].hit_off = before;
-                    slices[k].hit_cnt = lane->n_hits_total - before;
-                    slices[k].done = true;
+                    ranges[k].lane = lane;
+                    ranges[k].hit_off = before;
+                    ranges[k].hit_cnt = lane->n_hits_total - before;
+                    ranges[k].done = true;
                     last_done = k;
-                    max_len = std::max(max_len, sl.max_len);
-                    free_bufs.push_back(sl.buf);
+                    max_len = std::max(max_len, ml);
+                    busy_lanes--;
                     commit_ready();
                 }
                 cv.notify_all();
@@ -971,24 +1188,22 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
 
     commit_mu = &mu;
     std::vector<std::thread> th;
-    const uint64_t n_lanes_used = n >= ls.size() * kLaneMinReads ? ls.size() : 1;
-    lanes_used = n_lanes_used;
-    int n_up = kUploaders;
-    if (const char* e = getenv("MTSV_UPLOADERS")) n_up = std::max(1, std::min(kUploaders, atoi(e)));
-    for (int t = 0; t < n_up; t++) th.emplace_back(uploader, t);
+    th.emplace_back(feeder);
+    th.emplace_back(watcher);
     for (uint64_t i = 1; i < n_lanes_used; i++) th.emplace_back(lane_main, ls[i]);
     lane_main(this);
     for (auto& t : th) t.join();
     commit_mu = nullptr;
     if (trace) fprintf(stderr, "[run_host] threads joined at %.1f ms\n", (now_s() - run_t0) * 1e3);
     if (first_err) {
+        (void)hipStreamSynchronize(copy_stream);
         (void)hipStreamSynchronize(copy_stream2);
         std::rethrow_exception(first_err);
     }
     end_run();
     HIP_CHECK(hipStreamSynchronize(copy_stream2));
     staged_valid = staged_hits == total_hits;
-    if (trace) fprintf(stderr, "[run_host] hits on the host at %.1f ms (%llu slices); %.1f ms since the call began\n", (now_s() - run_t0) * 1e3, (unsigned long long)slices.size(), (now_s() - t_entry) * 1e3);
+    if (trace) fprintf(stderr, "[run_host] hits on the host at %.1f ms (%llu ranges, %llu chunks); %.1f ms since the call began\n", (now_s() - run_t0) * 1e3, (unsigned long long)ranges.size(), (unsigned long long)chunks.size(), (now_s() - t_entry) * 1e3);
     if (!staged_valid) throw std::runtime_error("internal: run_host staged " + std::to_string(staged_hits) + " of " + std::to_string(total_hits) + " hits");
 }
 

@@ -17,16 +17,22 @@ struct Batch {
     mtsv_hit* h_hits_stage = nullptr;  // pinned (pool): run_host copies every slice's hits here while later slices run
     uint64_t h_hits_cap = 0, staged_hits = 0, last_total_hits = 0;
     bool staged_valid = false;
-    // run_host: ring of input slices (device buffer + pinned staging each), filled by kUploaders threads
-    struct RingBuf {
+    // run_host: the input arenas in HBM (the whole host batch, or segments of it taking turns), filled in read order by one
+    // feeder thread on copy_stream; page-locked staging chunks for bases that lie in ordinary memory
+    struct Arena {
         uint8_t* d_bases = nullptr;
         uint32_t* d_off = nullptr;
-        uint8_t* h_bases = nullptr;
-        uint32_t* h_off = nullptr;
+        uint64_t cap_bases = 0, cap_reads = 0;
     };
-    static constexpr int kUploaders = 3;
-    std::vector<RingBuf> ring;
-    hipStream_t copy_streams[kUploaders] = {};
+    static constexpr uint64_t kArenaBases = 3ull << 30;   // offsets inside a segment are u32
+    static constexpr uint64_t kArenaReads = 1ull << 30;
+    Arena arena[2];
+    uint32_t* h_off_all = nullptr;  // pinned: the batch's offsets, narrowed to segment-relative u32
+    uint64_t h_off_cap = 0;
+    static constexpr int kStage = 4;
+    uint8_t* h_stage[kStage] = {};
+    hipStream_t copy_stream = nullptr;
+    std::vector<hipEvent_t> chunk_ev;  // one per copy chunk, kept between runs
     std::mutex* commit_mu = nullptr;  // set while run_host's threads may touch the lanes' result arrays
     uint64_t max_reads, max_bases, hit_cap, hits_cap = 0;
     uint64_t bytes = 0;
@@ -64,8 +70,9 @@ struct Batch {
     uint2* d_strip = nullptr;  // tiled long-read kernel: band hand-over strips, allocated when a pass first needs them
     uint64_t strip_cap = 0;
     uint64_t* h_counters = nullptr;  // pinned
-    hipEvent_t ev[13];  // [0..7] stage boundaries of a pass, [8..9] the lane's run, [10..11] around the prefilter kernels, [12] after k_sw_diag
-    float sw_ms_acc = 0, sweep_ms_acc = 0;
+    hipEvent_t ev[15];  // [0..7] stage boundaries of a pass, [8..9] the lane's run, [10..11] around the prefilter kernels, [12] after k_sw_diag,
+                        // [13] after the edit-distance bound, [14] after the first round's edit distances
+    float sw_ms_acc = 0, sweep_ms_acc = 0, diag_ms_acc = 0, bound_ms_acc = 0, edit_ms_acc = 0;
     uint64_t sw_passed_acc = 0;   // candidates k_sw_pairs sent on to the edit distance (all rounds and passes of the run)
 
     std::vector<uint32_t> h_read_off;

@@ -181,7 +181,13 @@ int mtsv_index_info(const mtsv_index* ix, mtsv_index_info_t* info) {
     info->sa_s = ix->host.s;
     info->file_bytes = ix->host.file_bytes;
     info->device_bytes = 0;
-    for (auto& kv : ix->dev) info->device_bytes = kv.second->bytes;
+    info->kmer_k = 0;
+    info->sa_full = 0;
+    for (auto& kv : ix->dev) {
+        info->device_bytes = kv.second->bytes;
+        info->kmer_k = kv.second->view.kmer_tab ? kv.second->view.kmer_k : 0;
+        info->sa_full = kv.second->view.sa_full ? 1 : 0;
+    }
     return MTSV_OK;
 }
 

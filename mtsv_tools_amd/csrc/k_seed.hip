@@ -12,10 +12,17 @@ namespace {
 // downstream reads codes; the reverse complement (binner.rs:115) is applied where a strand is read.
 // ---------------------------------------------------------------------------------------------
 __device__ inline uint32_t fast_code(uint32_t ch);
-__global__ __launch_bounds__(256) void k_normalise(const uint8_t* src, uint8_t* dst, uint64_t n_bytes) {
-    const uint64_t i = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
-    if (i >= n_bytes) return;
-    uint4 v = *reinterpret_cast<const uint4*>(src + i);  // both buffers are 16-byte aligned here and have 64 bytes of slack
+__global__ __launch_bounds__(256) void k_normalise(const uint8_t* src, uint8_t* dst, uint64_t lo, uint64_t hi) {
+    // bytes [lo, hi) of the buffers; the 16-byte groups at the two edges may be shared with a neighbouring range that
+    // another stream normalises in place at the same time, so only the range's own bytes of them are touched
+    const uint64_t i = (lo & ~15ull) + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= hi) return;
+    if (i < lo || i + 16 > hi) {
+        const uint64_t a = i < lo ? lo : i, b = i + 16 > hi ? hi : i + 16;
+        for (uint64_t q = a; q < b; q++) dst[q] = (uint8_t)fast_code(src[q]);
+        return;
+    }
+    uint4 v = *reinterpret_cast<const uint4*>(src + i);  // both buffers are 16-byte aligned
     uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -581,11 +588,21 @@ __global__ __launch_bounds__(256) void k_locate(DevIndexView ix, const uint32_t*
 // ---------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------
+namespace {
+// a few counters from HBM into mapped page-locked host memory (visible to the host once the stream is synchronised)
+__global__ void k_publish(const uint64_t* __restrict__ src, uint64_t* dst, uint32_t n) {
+    if (threadIdx.x < n) __hip_atomic_store(dst + threadIdx.x, src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+}  // namespace
+
+void launch_publish(hipStream_t s, const uint64_t* src, uint64_t* dst_host, uint32_t n) {
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, s, src, dst_host, n);
+}
+
 void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end) {
-    begin &= ~15ull;  // whole 16-byte groups (a neighbouring range may write the same codes into a shared group)
     if (end <= begin) return;
-    const uint64_t n = end - begin;
-    hipLaunchKernelGGL(k_normalise, dim3(cdiv((n + 15) / 16, 256)), dim3(256), 0, s, src + begin, dst + begin, n);
+    const uint64_t n = end - (begin & ~15ull);  // 16-byte groups, the first one aligned
+    hipLaunchKernelGGL(k_normalise, dim3(cdiv((n + 15) / 16, 256)), dim3(256), 0, s, src, dst, begin, end);
 }
 
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,

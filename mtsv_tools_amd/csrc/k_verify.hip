@@ -1346,6 +1346,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     const uint32_t lane = lane_id();
     const uint32_t* bases32 = reinterpret_cast<const uint32_t*>(a.bases);
     unsigned long long verified = 0, wbytes = 0;
+    uint32_t cols = 0, refuted = 0;  // columns this lane's recurrences advanced; bound mode: candidates it refuted
     // wave-uniform slice of the worklist, claimed 256 items at a time; a lane whose candidate passed
     // (or whose TaxId chain ended) takes the next item, a lane whose candidate failed keeps its read
     // and moves to the next candidate of the same TaxId (index.rs:393)
@@ -1465,7 +1466,8 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             int score = (int)L, best = (int)L;  // D[L][0] = L
             uint4 nxt4 = Wn ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 0) : make_uint4(0, 0, 0, 0);
             const uint32_t* lane_tab = &eq_tab[0][0][tid];
-            for (uint32_t j0 = 0; j0 < Wn; j0 += 16) {
+            uint32_t j0 = 0;
+            for (; j0 < Wn; j0 += 16) {
                 if (BOUND) {  // decided already: passes, or the last row cannot come down to 2*ED any more
                     if (best <= (int)ED) break;
                     if (best > 2 * (int)ED && score - (int)(Wn - j0) > 2 * (int)ED) break;
@@ -1502,6 +1504,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     }
                 }
             }
+            cols += min(j0, Wn);
             if (!LIST && (!BOUND || !counted)) {
                 verified++;
                 wbytes += Wn;
@@ -1518,6 +1521,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     vg = g;
                     active = false;
                 } else {  // refuted: index.rs:406 fails
+                    refuted++;
                     a.cand_status[g] = 1;
                     const uint32_t nxt = a.cand_next[g];
                     if (nxt == 0xffffffffu || nxt >= maxc) active = false;
@@ -1565,6 +1569,17 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     if (lane == 0 && verified) {
         atomicAdd(a.n_verified, verified);
         atomicAdd(a.window_bytes, wbytes);
+    }
+    if (a.myers_ctr) {  // [0] columns (of W words each) advanced, [1] candidates refuted by the bound
+        unsigned long long c64 = cols, r64 = refuted;
+        for (int d = 32; d > 0; d >>= 1) {
+            c64 += __shfl_down(c64, d);
+            r64 += __shfl_down(r64, d);
+        }
+        if (lane == 0) {
+            atomicAdd(a.myers_ctr, c64);
+            if (BOUND && r64) atomicAdd(a.myers_ctr + 1, r64);
+        }
     }
 }
 

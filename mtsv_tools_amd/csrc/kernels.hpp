@@ -68,7 +68,8 @@ struct EvalArgs {
     uint32_t* pass_count = nullptr;
     uint32_t* next_list = nullptr;
     uint32_t* next_count = nullptr;
-    uint32_t* und_list = nullptr;  // k_sw_pairs TOP: candidates the covered rows do not decide
+    unsigned long long* myers_ctr = nullptr;  // k_edit_myers: [0] += columns its recurrences advanced, [1] += candidates its bound refuted
+    uint32_t* und_list = nullptr;  // k_sw_pairs TOP / k_edit_myers bound mode: candidates they do not decide
     uint32_t und_slot = 0;
     // tiled long-read kernel: one strip of strip_len window columns per 16-lane group (bottom row of a band)
     uint2* strip = nullptr;
@@ -81,6 +82,8 @@ struct EvalArgs {
 constexpr uint32_t kMaxRegisterReadLen = 256;  // 16 lanes x 16 read rows per lane: k_evaluate with the whole matrix band in registers
 constexpr uint32_t kMaxReadLen = 32767;        // the tiled kernel's packed 16-bit cells (edit distance <= read length)
 
+// n <= 64 counters from HBM into mapped page-locked host memory, by a kernel on stream s (no copy engine involved)
+void launch_publish(hipStream_t s, const uint64_t* src, uint64_t* dst_host, uint32_t n);
 // base normalisation of bytes [begin, end) of a read buffer, src -> dst (may be equal): every other kernel expects codes
 void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end);
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,

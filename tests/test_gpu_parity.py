@@ -742,3 +742,103 @@ def test_randomised_soak_short(tmp_path):
     spec.loader.exec_module(fz)
     for it in range(25):
         fz.one(it, random.Random(7 * 100003 + it), str(tmp_path))
+
+
+def test_reupload_with_other_flags_between_bin_batch_calls(small_db):
+    """mtsv_bin_batch keeps a workspace on the index handle; mtsv_index_to_device with other flags retires the
+    device structures that workspace points at.  bin_batch -> to_device(other flags) -> bin_batch on the same
+    handle, in a cycle and twice over, must give the oracle's hits every time (a use-after-free on the cached
+    workspace's mutex aborted the process here once, round 2)."""
+    ix, orc = small_db
+    bases, off = M.synth_reads(ix, seed=77, n_reads=2500, read_len=150)
+    want, _ = orc.bin_batch(bases, off, O.default_params(), threads=8)
+    assert len(want) > 1000
+    for _ in range(2):
+        for flags in (ALL_FLAGS[3], ALL_FLAGS[0], ALL_FLAGS[1], ALL_FLAGS[3], ALL_FLAGS[2]):
+            ix.to_device(0, flags)
+            assert_same_hits(ix.bin_batch(bases, off, M.default_params(), device=0), want)
+            assert_same_hits(ix.bin_batch(bases, off, M.default_params(), device=0), want)  # the cached workspace
+
+
+def _edited_read(rng, src, n_sub, n_del, n_ins):
+    """src with n_sub substitutions, n_del bases of src left out and n_ins bases added, at distinct spread-out places
+    (outside the first and last 20 bases, so that seeds at both ends keep the window where it belongs)."""
+    s = bytearray(src)
+    places = rng.sample(range(20, len(s) - 20, 3), n_sub + n_del + n_ins)
+    ops = [0] * n_sub + [1] * n_del + [2] * n_ins
+    for at, op in sorted(zip(places, ops), reverse=True):
+        if op == 0:
+            s[at] = rng.choice([c for c in b"ACGT" if c != s[at]])
+        elif op == 1:
+            del s[at]
+        else:
+            s.insert(at, rng.choice(b"ACGT"))
+    return bytes(s)
+
+
+def test_edit_distance_bound_of_the_prefilter_in_all_three_outcomes(tmp_path, monkeypatch):
+    """k_edit_myers in bound mode decides the SW predicate of index.rs:406 from the unit-cost edit distance D under
+    the SW matrix's matches: D <= ED passes, D > 2*ED refutes, in between the sweep decides.  Reads built to land in
+    each class, candidates that k_sw_diag's seed-diagonal bounds cannot decide (several indels):
+      * few edits with indels                      -> D <= ED: passes, a hit;
+      * 14 bases of the reference left out + 8 substitutions: score = L - 2*8 - 14 >= L - 2*ED but D = 22 > ED
+        -> undecided by the bound, passed by the sweep, refused by the edit distance (index.rs:410);
+      * 26 substitutions: D = 26 in (ED, 2*ED], score = L - 52 < threshold -> undecided, refuted by the sweep;
+      * unrelated reads sharing one 18-mer with the database -> D > 2*ED: refuted by the bound alone;
+      * the same with N in the read (N matches N in the SW matrix and nothing in the edit distance).
+    Hits, candidates examined and the number passed on to the edit distance equal the oracle's; the device counters
+    show that every route was taken."""
+    rng = random.Random(99)
+    entries = [(10 + t, 500 + t, helpers.rnd_seq(rng, 6000)) for t in range(6)]
+    # an N run inside the last sequence: reads across it hold N that face N
+    body = bytearray(entries[5][2])
+    body[3000:3012] = b"N" * 12
+    entries[5] = (15, 505, bytes(body))
+    ix = M.MGIndex.build(entries, threads=4)
+    p = str(tmp_path / "bound.idx")
+    ix.write(p)
+    orc = O.Index.read(p)
+    L = 150
+    reads = []
+    for i in range(400):
+        t = entries[rng.randrange(6)][2]
+        st = rng.randrange(0, len(t) - L - 40)
+        kind = i % 5
+        if kind == 0:
+            r = _edited_read(rng, t[st:st + L + 4], 3, 4, 2)[:L]
+        elif kind == 1:
+            r = _edited_read(rng, t[st:st + L + 14], 8, 14, 0)[:L]
+        elif kind == 2:
+            r = _edited_read(rng, t[st:st + L], 26, 0, 0)
+        elif kind == 3:
+            r = bytearray(helpers.rnd_seq(rng, L))
+            at = rng.randrange(0, 8) * 15
+            r[at:at + 18] = t[st:st + 18]
+            r = bytes(r)
+        else:
+            t5 = entries[5][2]
+            st5 = rng.randrange(2900, 2990)
+            r = _edited_read(rng, t5[st5:st5 + L + 3], 2, 3, 1)[:L]
+        reads.append(r if rng.random() < 0.5 else helpers.revcomp(r))
+    mp, op = both_params()
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want, ctr = orc.bin_batch(bases, off, op, threads=8)
+    assert len(want) > 100
+    ref = None
+    for bound in ("1", "0"):
+        monkeypatch.setenv("MTSV_SW_BOUND", bound)
+        b = M.Batch(ix, 0, len(reads), len(bases))
+        b.upload(bases, off)
+        b.run(mp)
+        assert_same_hits(b.download(), want)
+        st = b.stats()
+        assert (st["n_verified"], st["window_bytes"], st["n_sw_passed"]) == (ctr["n_sw"], ctr["W"], ctr["n_edit"])
+        assert st["n_sw_passed"] > st["n_hits"]              # passed the prefilter, refused by the edit distance
+        if bound == "1":
+            assert st["n_sw_bound_refuted"] > 50             # refuted without a sweep
+            assert st["sw_cell_pairs"] > 0                   # and some left to the sweep
+            ref = st["sw_cell_pairs"]
+        else:
+            assert st["n_sw_bound_refuted"] == 0 and st["sw_cell_pairs"] > ref
+        b.close()

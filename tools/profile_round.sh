@@ -25,5 +25,5 @@ echo "sq done"
 cd $ROOT
 python3 tools/profile_summary.py trace $OUT/trace $OUT/kernel_stats.csv
 python3 tools/profile_summary.py pmc $OUT/fetch $OUT/write $WL $OUT/hbm_pmc.json $OUT/hbm_traffic.json
-python3 tools/profile_summary.py sq $OUT/sq $OUT/trace $OUT/sq_counters.txt
+python3 tools/profile_summary.py sq $OUT/sq $OUT/trace $OUT/sq_counters.txt $OUT/hbm_traffic.json
 rm -rf $OUT/fetch $OUT/write $OUT/sq   # raw counter CSVs are large

@@ -13,7 +13,8 @@ import os
 import re
 import sys
 
-ROUND = os.environ.get("MTSV_PROFILE_ROUND", "r02")
+ROUND = os.environ.get("MTSV_PROFILE_ROUND", "r03")
+COMMIT = os.environ.get("MTSV_PROFILE_COMMIT", "unknown")
 
 
 def norm(name):
@@ -66,7 +67,8 @@ def pmc(dfetch, dwrite, workload, out, traffic):
         w = sum(v["sum"] for k, v in per["WRITE_SIZE_KB"].items() if k.startswith(prefix))
         return (f + w) * 1024 / passes
     summary = {
-        "workload": workload, "dev_flags": 0, "k_sw_pairs_bytes_per_step": kernel_bytes("k_sw_pairs"),
+        "workload": workload, "dev_flags": 0, "commit": COMMIT, "k_sw_pairs_bytes_per_step": kernel_bytes("k_sw_pairs"),
+        "k_edit_myers_bytes_per_step": kernel_bytes("k_edit_myers"),
         "k_search_bytes_per_step": kernel_bytes("k_search"),
         "source": f"{os.path.join('profiles', ROUND + '_' + workload + '_hbm_pmc.json')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, `MTSV_LANES=1 bench.py --resident-only`; per-step = per-kernel sums / pipeline passes in the profiled process)",
         "fetch_bytes_per_step_raw": fetch, "write_bytes_per_step": write, "hbm_bytes_per_step": fetch + write,
@@ -78,7 +80,7 @@ def pmc(dfetch, dwrite, workload, out, traffic):
     print(f"{passes} passes: fetch {fetch / 1e9:.1f} GB, write {write / 1e9:.1f} GB per step")
 
 
-def sq(dsq, dtrace, out):
+def sq(dsq, dtrace, out, traffic=None):
     """SQ counters per pipeline kernel (sums over its launches in the profiled process) next to its duration in the
     same process' kernel trace; VALU rate = SQ_INSTS_VALU / 1024 SIMDs / duration."""
     acc = collections.defaultdict(lambda: collections.defaultdict(float))
@@ -91,7 +93,7 @@ def sq(dsq, dtrace, out):
         f.write("MTSV_LANES=1 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY "
                 "SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES\n  -- python3 bench.py --steps 1 --warmup 0 --resident-only     (one whole-batch pipeline pass; "
                 "sums over a kernel's launches; durations from the same profiled process)\n"
-                "VALU rate = SQ_INSTS_VALU / 1024 SIMDs / duration; issue ceiling of the chip ~540 wave-instr/us/SIMD (profiles/r01_valu_issue_rate.txt)\n")
+                "VALU rate = SQ_INSTS_VALU / 1024 SIMDs / duration; architectural ceiling 600 wave-instr/us/SIMD (one wave64 VALU op per 4 cycles at 2.4 GHz)\n")
         for k in sorted(dur, key=lambda k: -dur[k]):
             if not k.startswith("k_") or k in ("k_expand_sa", "k_kmer_level", "k_kmer_level1"):
                 continue
@@ -102,12 +104,19 @@ def sq(dsq, dtrace, out):
             f.write(f"{k:28s} {dur[k]:7.2f} ms  VALU {valu:.3g} ({rate:.0f}/us/SIMD)  SALU {c.get('SQ_INSTS_SALU', 0):.3g}  "
                     f"LDS {c.get('SQ_INSTS_LDS', 0):.3g}  VMEM_RD {c.get('SQ_INSTS_VMEM_RD', 0):.3g}  SQ_WAIT_INST_ANY/SQ_WAVE_CYCLES {wait:.2f}\n")
     print("wrote", out)
+    if traffic and os.path.exists(traffic):  # what bench.py quotes as roofline.valu.issued_frac
+        t = json.load(open(traffic))
+        passes = 1  # the SQ run is one step
+        my = [k for k in dur if k.startswith("k_edit_myers")]
+        t["k_edit_myers_valu_per_step"] = sum(acc[k].get("SQ_INSTS_VALU", 0.0) for k in my) / passes
+        t["k_edit_myers_ms_per_step"] = sum(dur[k] for k in my) / passes
+        json.dump(t, open(traffic, "w"), indent=1)
 
 
 if __name__ == "__main__":
     if sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "sq":
-        sq(sys.argv[2], sys.argv[3], sys.argv[4])
+        sq(*sys.argv[2:6])
     else:
         pmc(*sys.argv[2:7])
