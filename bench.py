@@ -81,6 +81,204 @@ def host_description():
     return d
 
 
+CHUNK_SPEC = (128, 4, 674_000, 10_000_000, 150)  # per chunk: taxa, GIs per taxon, sequence length; reads of the whole job, read length
+
+
+def merge_by_read(per_chunk):
+    """per-chunk hit arrays -> one list ordered by (read, chunk): what mtsv_bin_batch_chunks returns"""
+    allh = np.concatenate(per_chunk)
+    chunk = np.concatenate([np.full(len(h), c) for c, h in enumerate(per_chunk)])
+    return allh[np.lexsort((chunk, allh["read"]))]
+
+
+def main_chunks(args):
+    """BASELINE config 5 (SURVEY 8(e) Mode B): 8 MG-index chunks of 1/8 of the 10 GB database each, one per GPU, every
+    chunk sees every read; the per-chunk hit lists are merged per read (what mtsv-collapse makes of the per-chunk result
+    files, README.md:189, collapse.rs:597-625).  A step = host bases in -> merged host hits out for ALL reads.
+      one process (--gpus 1): all chunks resident on this GPU, one call of mtsv_bin_batch_chunks per step (the merge is
+          inside the timed call);
+      torchrun, N ranks: rank r holds chunk r of N on its own GPU and bins every read against it (timed: max over
+          ranks); afterwards every rank writes its result lines and rank 0 merges the N files with bin/mtsv-collapse,
+          timed separately (`collapse_s`) -- the reference's own workflow for this configuration."""
+    import ctypes
+    import subprocess
+
+    import torch
+    import torch.distributed as dist
+
+    import mtsv_tools_amd as M
+    from mtsv_tools_amd import _lib as L
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available() or M.device_count() < 1:
+        sys.exit("bench.py needs a HIP device: libmtsv_amd has no CPU path")
+    shared_gpu = os.environ.get("MTSV_BENCH_SHARE_GPU") == "1"
+    if shared_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo" if shared_gpu else "nccl", **({} if shared_gpu else {"device_id": torch.device("cuda", local_rank)}))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n_taxa, gis, seq_len, n_reads, read_len = CHUNK_SPEC
+    if args.reads:
+        n_reads = args.reads
+    n_chunks = world if world > 1 else args.chunks
+    mine = [rank] if world > 1 else list(range(n_chunks))
+    ncpu = os.cpu_count() or 8
+    paths = [f"/tmp/mtsv_bench_config5_c{c}of{n_chunks}.idx" for c in range(n_chunks)]
+    t0 = time.time()
+    for c in mine:  # untimed setup: every chunk is its own synthetic database (seed per chunk), built on this rank's GPU
+        expect_n = n_taxa * gis * seq_len + 1
+        ok = False
+        try:
+            ok = os.path.exists(paths[c]) and int.from_bytes(open(paths[c], "rb").read(8), "little") == expect_n
+        except OSError:
+            pass
+        if not ok:
+            M.set_build_device(local_rank)
+            ixb = M.MGIndex.synth(SEED_DB + 101 * (c + 1), n_taxa, gis, seq_len, threads=min(32, ncpu))
+            M.set_build_device(-1)
+            ixb.write(paths[c] + ".tmp")
+            ixb.close()
+            os.replace(paths[c] + ".tmp", paths[c])
+    t_build = time.time() - t0
+    barrier()
+    chunks = {}
+    for c in mine:
+        chunks[c] = M.MGIndex.load(paths[c])
+        chunks[c].to_device(local_rank, args.dev_flags)
+    # reads: an equal share sampled from every chunk (seeded), concatenated in chunk order; every rank ends up with all of them
+    share = [n_reads // n_chunks + (1 if c < n_reads % n_chunks else 0) for c in range(n_chunks)]
+    parts = {c: M.synth_reads(chunks[c], seed=2000 + c, n_reads=share[c], read_len=read_len)[0] for c in mine}
+    if world > 1:
+        buf = [torch.empty(share[c] * read_len, dtype=torch.uint8, device="cpu" if shared_gpu else "cuda") for c in range(n_chunks)]
+        mine_t = torch.from_numpy(parts[rank]).to(buf[0].device)
+        for c in range(n_chunks):  # (shares differ by at most one read: broadcast per chunk instead of a padded all_gather)
+            if c == rank:
+                buf[c].copy_(mine_t)
+            dist.broadcast(buf[c], src=c)
+        bases = torch.cat(buf).cpu().numpy()
+        del buf
+    else:
+        bases = np.concatenate([parts[c] for c in range(n_chunks)])
+    off = (np.arange(n_reads + 1, dtype=np.uint64) * read_len)
+    params = M.default_params()
+    pinned = M.HostBuffer(len(bases))
+    pinned.array[:] = bases
+    bases_p, off_p = pinned.array.ctypes.data, off.ctypes.data
+    HIT_FIELDS = ("read", "tax_id", "gi", "edit", "strand", "offset")
+
+    if world == 1:
+        handles = (ctypes.c_void_p * n_chunks)(*[chunks[c].h for c in range(n_chunks)])
+        devs = (ctypes.c_int * n_chunks)(*([local_rank] * n_chunks))
+
+        def step(keep=False):
+            out_p, out_n = ctypes.c_void_p(), ctypes.c_uint64()
+            L._check(M.lib().mtsv_bin_batch_chunks(handles, devs, n_chunks, bases_p, off_p, n_reads, ctypes.byref(params),
+                                                   ctypes.byref(out_p), ctypes.byref(out_n)))
+            if keep:
+                return L._hits_from(out_p, out_n.value)
+            M.lib().mtsv_hits_free(out_p)
+    else:
+        slice_reads = M.bin_batch_slice_reads(n_reads)
+        hb = M.Batch(chunks[rank], local_rank, min(n_reads, slice_reads), min(len(bases), slice_reads * (read_len + 8)))
+
+        def step(keep=False):
+            L._check(M.lib().mtsv_batch_run_host(hb.h, bases_p, off_p, n_reads, ctypes.byref(params)))
+            out_p, out_n = ctypes.c_void_p(), ctypes.c_uint64()
+            L._check(M.lib().mtsv_batch_download(hb.h, ctypes.byref(out_p), ctypes.byref(out_n)))
+            if keep:
+                return L._hits_from(out_p, out_n.value)
+            M.lib().mtsv_hits_free(out_p)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    each_ms = []
+    for _ in range(args.steps):
+        t_s = time.perf_counter()
+        step()
+        each_ms.append(round((time.perf_counter() - t_s) * 1e3, 2))
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    hits = step(keep=True)  # untimed: what the checks and the collapse leg look at
+
+    # ---- parity on a sample of the reads (every (n/ns)-th read, so that every chunk's reads are in it) ----
+    ns = min(args.cpu_sample // 4, n_reads)
+    idx = (np.arange(ns, dtype=np.int64) * (n_reads // ns))
+    sample = bases.reshape(n_reads, read_len)[idx].reshape(-1)
+    soff = (np.arange(ns + 1, dtype=np.uint64) * read_len)
+    remap = np.full(n_reads, -1, dtype=np.int64)
+    remap[idx] = np.arange(ns)
+    mine_sample = hits[remap[hits["read"].astype(np.int64)] >= 0].copy()
+    mine_sample["read"] = remap[mine_sample["read"].astype(np.int64)]
+    parity, cpu, collapse = "not checked", None, None
+    gathered = [mine_sample]
+    if world > 1:
+        gathered = [None] * world if rank == 0 else None
+        dist.gather_object(mine_sample, gathered, dst=0)
+        # the reference's workflow: a results file per chunk, merged by mtsv-collapse
+        ids = [f"r{i}" for i in range(n_reads)] if n_reads <= 2_000_000 else None
+        if ids is not None:
+            res = f"/tmp/mtsv_bench_config5_results_{rank}.txt"
+            open(res, "w").write(M.format_results(hits, ids, False))
+            dist.barrier()
+            if rank == 0:
+                t0 = time.perf_counter()
+                subprocess.check_call([os.path.join(ROOT, "mtsv_tools_amd", "bin", "mtsv-collapse"), "-o", "/tmp/mtsv_bench_config5_collapsed.txt"]
+                                      + [f"/tmp/mtsv_bench_config5_results_{r}.txt" for r in range(world)])
+                collapse = {"collapse_s": time.perf_counter() - t0, "files": world,
+                            "lines": sum(1 for _ in open("/tmp/mtsv_bench_config5_collapsed.txt"))}
+    if rank == 0 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+        got = merge_by_read(gathered) if world > 1 else mine_sample
+        cores = max(1, min(ncpu, args.cpu_threads or 16))
+        t0 = time.perf_counter()
+        per = [O.Index.read(paths[c]).bin_batch(sample, soff, O.default_params(), threads=cores)[0] for c in range(n_chunks)]
+        dt = time.perf_counter() - t0
+        want = merge_by_read(per)
+        same = len(got) == len(want) and all(np.array_equal(got[f], want[f]) for f in HIT_FIELDS)
+        parity = f"{'identical' if same else 'MISMATCH'} on {ns} sampled reads x {n_chunks} chunks ({len(want)} merged hits)"
+        cpu = {"value": ns / dt, "unit": "reads/s", "cores": cores, "kind": "port", "host": host_description(),
+               "sample": f"{ns} reads (every {n_reads // ns}-th) against all {n_chunks} chunks one after the other, oracle/libmtsv_oracle.so, {cores} OpenMP threads, {dt:.1f} s"}
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
+        if "MISMATCH" in parity:
+            print(json.dumps({"error": "parity", "parity": parity}))
+            raise SystemExit("bench: merged GPU hits differ from the oracle's: " + parity)
+        info = chunks[mine[0]].info()
+        out = {"metric": "reads/sec (whole node), 150bp reads vs MG-index", "value": n_reads * args.steps / elapsed, "unit": "reads/s",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32/i16", "data": "synthetic",
+               "value_region": ("one call of mtsv_bin_batch_chunks per step: host bases in -> per-read merged host hits out, all chunks on one GPU"
+                                if world == 1 else "every rank: mtsv_batch_run_host + mtsv_batch_download of ALL reads against its chunk; max over ranks; "
+                                                   "the merge of the per-chunk results (mtsv-collapse) is timed separately"),
+               "step_ms_each": each_ms,
+               "config": {"workload": f"config5: {n_reads} x {read_len}bp reads vs {n_chunks} MG-index chunks of n={info['n']:.3g} each",
+                          "mode": "chunks (SURVEY 8(e) Mode B)", "chunks": n_chunks, "reads_per_step": n_reads, "read_len": read_len,
+                          "chunk_symbols": info["n"], "chunk_hbm_bytes": info["device_bytes"], "chunk_kmer_k": info.get("kmer_k"),
+                          "parallelism": f"{n_chunks} database chunks x {world} GPU(s), reads broadcast, hits merged per read; no collective on the data path"},
+               "n_hits_merged": int(len(hits)) if world == 1 else None, "collapse": collapse,
+               "cpu_baseline": cpu, "parity": parity, "setup_s": {"chunk_build": t_build}}
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -101,7 +299,13 @@ def main():
                     help="time the steps on reads in ordinary (pageable) host memory instead of memory from mtsv_host_alloc")
     ap.add_argument("--verify-mode", type=int, default=0, help="0: reference order (SW + edit per candidate), 1: edit first")
     ap.add_argument("--dev-flags", type=int, default=0, help="MTSV_DEV_* flags (1: sampled SA only, 2: no k-mer table)")
+    ap.add_argument("--mode", default="reads", choices=["reads", "chunks"],
+                    help="reads (default): BASELINE configs 1-4, index replicated per GPU, reads sharded.  chunks: BASELINE config 5, "
+                         "the database in chunks (one per GPU), every chunk sees every read, hits merged per read")
+    ap.add_argument("--chunks", type=int, default=8, help="--mode chunks on one GPU: database chunks, all resident on that GPU")
     args = ap.parse_args()
+    if args.mode == "chunks":
+        return main_chunks(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -625,7 +625,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
                         sw.worklist = sw.und_list;
                         sw.wl_count_slot = 17;
                     }
-                    launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag);
+                    launch_sw_pairs(stream, v, sw, items, pass_max_len, sw_diag, false, round == 0 && sw_bound);
 #ifdef MTSV_SW_HIST
                     {
                         static uint32_t hh[768];
@@ -912,7 +912,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     if (trace) fprintf(stderr, "[run_host] entered; begin_run at %.2f ms\n", (now_s() - t_entry) * 1e3);
     begin_run(p);
     staged_hits = 0;
-    if (!h_hits_stage) {
+    if (!h_hits_stage && !keep_on_device) {
         // expect about as many hits as the last run produced (first run: one per read)
         // (a fresh page-locked array costs ~60 us per MB to create and is slow on its first copy: ask for little more than
         //  the last batch needed, so that the array that batch returned to the pool fits again)
@@ -1075,7 +1075,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     auto commit_ready = [&]() {  // mu held: hits of finished ranges leave for the host in read order
         while (next_commit < ranges.size() && ranges[next_commit].done) {
             Range& rg = ranges[next_commit];
-            if (rg.hit_cnt) {
+            if (rg.hit_cnt && !keep_on_device) {
                 stage_reserve(staged_hits + rg.hit_cnt);
                 HIP_CHECK(hipMemcpyAsync(h_hits_stage + staged_hits, rg.lane->d_hits + rg.hit_off, rg.hit_cnt * sizeof(mtsv_hit),
                                          hipMemcpyDeviceToHost, copy_stream2));
@@ -1088,7 +1088,6 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     };
     uint64_t ramp_floor = 256 << 10;
     if (const char* e = getenv("MTSV_RAMP_FLOOR")) ramp_floor = std::max<uint64_t>(4096, strtoull(e, nullptr, 10));
-    const bool greedy = getenv("MTSV_TAKE_GREEDY") != nullptr;
     uint64_t idle_take = 64 << 10;  // an idle device starts on this little
     if (const char* e = getenv("MTSV_IDLE_TAKE")) idle_take = std::max<uint64_t>(1024, strtoull(e, nullptr, 10));
     auto lane_main = [&](Batch* lane) {
@@ -1103,7 +1102,7 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     // The lane's result array only has to hold hits until they have left for the host: once it is half
                     // full and everything in it has been committed, start again at its beginning (a 100 M-read host
                     // batch would otherwise pile a third of its hits up on the device).
-                    if (lane->n_hits_total > lane->hits_cap / 2 && (last_done == ~0ull || last_done < next_commit)) {
+                    if (!keep_on_device && lane->n_hits_total > lane->hits_cap / 2 && (last_done == ~0ull || last_done < next_commit)) {
                         HIP_CHECK(hipStreamSynchronize(copy_stream2));
                         lane->n_hits_total = 0;
                     }
@@ -1125,20 +1124,9 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                             want = std::min(ws_reads, std::min(up, down));
                         }
                         uint64_t take = 0;
-                        if (greedy) {
-                            // everything that has arrived, once it is worth a pass; the last reads in equal parts
-                            const uint64_t floor_reads = std::min<uint64_t>(ws_reads, ramp_floor);
-                            const uint64_t left = n - next_read;
-                            if (all_arrived || arrived >= seg_end) {
-                                const uint64_t parts = std::max<uint64_t>(1, std::min<uint64_t>(n_lanes_used, (avail + floor_reads - 1) / floor_reads));
-                                take = std::min(ws_reads, (avail + parts - 1) / parts);
-                            } else if (avail >= std::min(floor_reads, left)) take = std::min(ws_reads, avail);
-                            else if (busy_lanes == 0 && avail >= std::min(idle_take, left)) take = avail;
-                        } else {
                         if (avail >= want) take = want;
                         else if (avail && (all_arrived || arrived >= seg_end)) take = avail;            // nothing more will come for it
                         else if (busy_lanes == 0 && avail >= std::min(idle_take, want)) take = avail;  // do not leave the device idle
-                        }
                         if (take) {
                             rb = next_read;
                             re = next_read + take;
@@ -1202,9 +1190,9 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
     }
     end_run();
     HIP_CHECK(hipStreamSynchronize(copy_stream2));
-    staged_valid = staged_hits == total_hits;
+    staged_valid = !keep_on_device && staged_hits == total_hits;
     if (trace) fprintf(stderr, "[run_host] hits on the host at %.1f ms (%llu ranges, %llu chunks); %.1f ms since the call began\n", (now_s() - run_t0) * 1e3, (unsigned long long)ranges.size(), (unsigned long long)chunks.size(), (now_s() - t_entry) * 1e3);
-    if (!staged_valid) throw std::runtime_error("internal: run_host staged " + std::to_string(staged_hits) + " of " + std::to_string(total_hits) + " hits");
+    if (!staged_valid && !keep_on_device) throw std::runtime_error("internal: run_host staged " + std::to_string(staged_hits) + " of " + std::to_string(total_hits) + " hits");
 }
 
 // pinned result array of run_host: grown geometrically through the pool (mu of run_host held)
@@ -1246,6 +1234,20 @@ void Batch::download(mtsv_hit** hits, uint64_t* n) {
     }
     *hits = h;
     *n = total_hits;
+}
+
+void Batch::download_into(mtsv_hit* dst, uint64_t n) {
+    HIP_CHECK(hipSetDevice(di->device));
+    if (n != total_hits) throw std::runtime_error("internal: download_into of " + std::to_string(n) + " hits, the run produced " + std::to_string(total_hits));
+    last_total_hits = total_hits;
+    hipStream_t cs = copy_stream2 ? copy_stream2 : stream;
+    uint64_t at = 0;
+    for (auto& sg : segments) {
+        if (!sg.count) continue;
+        HIP_CHECK(hipMemcpyAsync(dst + at, sg.lane->d_hits + sg.offset, sg.count * sizeof(mtsv_hit), hipMemcpyDeviceToHost, cs));
+        at += sg.count;
+    }
+    HIP_CHECK(hipStreamSynchronize(cs));
 }
 
 }  // namespace mtsv

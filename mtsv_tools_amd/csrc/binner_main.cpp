@@ -421,18 +421,41 @@ int main(int argc, char** argv) {
         bool use_gz = false;
         // inflating is the expensive part of gzip input: more helpers than plain text needs (measured: 8 threads 3.3 M
         // reads/s, 16 5.5, 32 5.7 against 1.3 on zlib's one stream)
+        // (-t / --threads bounds it like every other host-side pool; MTSV_GZ_THREADS=16 is what the 9.0 M reads/s were measured with)
         unsigned gz_threads = host_threads;
-        if (!getenv("MTSV_HOST_THREADS")) gz_threads = std::min(std::max(host_threads, 16u), std::max(1u, std::thread::hardware_concurrency()));  // (9.0 M reads/s at 16, 7.9 at 32 on the GPU box)
-        const uint64_t ingest_block = getenv("MTSV_INGEST_BLOCK") ? strtoull(getenv("MTSV_INGEST_BLOCK"), nullptr, 10) : (16ull << 20);
+        if (const char* e = getenv("MTSV_GZ_THREADS")) gz_threads = (unsigned)std::max(1, atoi(e));
+        gz_threads = std::min(gz_threads, std::max(1u, std::thread::hardware_concurrency()));
+        // Plain input is cut into blocks of about one batch of reads each (bytes per record estimated from the file's
+        // head): a parsed block then IS the batch -- its bases lie in page-locked memory (byte_alloc) that the copy
+        // engine reads in place, and the producer thread hands it on without touching the bases again.
+        uint64_t ingest_block = 16ull << 20;
+        if (getenv("MTSV_INGEST_BLOCK")) ingest_block = strtoull(getenv("MTSV_INGEST_BLOCK"), nullptr, 10);
+        else if (FILE* hf = fopen(input.c_str(), "rb")) {
+            std::vector<char> head(256 << 10);
+            const size_t got = fread(head.data(), 1, head.size(), hf);
+            fclose(hf);
+            uint64_t recs = 0;
+            if (got >= 2 && !((uint8_t)head[0] == 0x1f && (uint8_t)head[1] == 0x8b)) {
+                if (fastq) {
+                    uint64_t lines = 0;
+                    for (size_t i = 0; i < got; i++) lines += head[i] == '\n';
+                    recs = lines / 4;
+                } else {
+                    for (size_t i = 0; i < got; i++) recs += head[i] == '>' && (i == 0 || head[i - 1] == '\n');
+                }
+            }
+            if (recs >= 8) ingest_block = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)got / (double)recs * (double)batch_reads), 4ull << 20), 256ull << 20);
+        }
         bool serial_from_start = getenv("MTSV_SERIAL_INGEST") != nullptr || !par.open(input, fastq, host_threads, ingest_block);
         if (serial_from_start && !getenv("MTSV_SERIAL_INGEST") && !getenv("MTSV_SERIAL_GZIP") && gzpar.open(input, fastq, gz_threads, ingest_block)) {
             use_gz = true;
             serial_from_start = false;
         }
         if (!serial_from_start) {
-            ReadBlock blk;
+            auto blk_owner = pool.get();
             uint64_t irregular = 0;
             for (;;) {
+                ReadBlock& blk = *blk_owner;
                 auto r = use_gz ? gzpar.next(blk, &irregular) : par.next(blk, &irregular);
                 if (r == mtsv_ingest::ParallelFastx::END) break;
                 if (r == mtsv_ingest::ParallelFastx::IRREGULAR) {
@@ -448,6 +471,12 @@ int main(int argc, char** argv) {
                 if (skipped < read_offset) {
                     from = std::min<uint64_t>(read_offset - skipped, blk.n());
                     skipped += from;
+                }
+                // a block of about a batch, nothing pending: the block is the batch
+                if (from == 0 && w->n() == 0 && blk.n() && blk.n() <= batch_reads + batch_reads / 2 && blk.bases.size() < (1ull << 30)) {
+                    if (!emit(std::move(blk_owner))) return true;
+                    blk_owner = pool.get();
+                    continue;
                 }
                 // cut the block at batch boundaries
                 while (from < blk.n()) {
@@ -486,7 +515,7 @@ int main(int argc, char** argv) {
                 skipped++;
                 continue;
             }
-            w->bases.insert(w->bases.end(), r.seq.begin(), r.seq.end());
+            w->bases.insert(w->bases.end(), (const uint8_t*)r.seq.data(), (const uint8_t*)r.seq.data() + r.seq.size());
             w->off.push_back(w->bases.size());
             w->ids += r.id;
             w->ids.push_back('\0');
@@ -565,6 +594,9 @@ int main(int argc, char** argv) {
                 return 2;
             }
     }
+    // parsed blocks land in page-locked memory from here on: the GPU copies them from where the parser put them
+    mtsv_ingest::byte_alloc().alloc = [](size_t n) { return mtsv_host_alloc(n); };
+    mtsv_ingest::byte_alloc().release = [](void* q) { mtsv_host_free(q); };
     logmsg("INFO", "Beginning queries.");
     struct timespec w0;
     clock_gettime(CLOCK_MONOTONIC, &w0);
@@ -681,6 +713,10 @@ int main(int argc, char** argv) {
             std::unique_lock<std::mutex> lk(mu);
             idle.wait(lk, [&] { return q.empty() && running == 0; });
         }
+        void wait_below(size_t n) {  // until fewer than n jobs are queued or running
+            std::unique_lock<std::mutex> lk(mu);
+            idle.wait(lk, [&] { return q.size() + running < n; });
+        }
         ~Helpers() {
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -754,12 +790,13 @@ int main(int argc, char** argv) {
                     char* tx = text[k];
                     const uint64_t ln = len[k];
                     text[k] = nullptr;  // the write job owns it now
-                    write_pool.submit([tx, ln, at, out_fd, &write_failed] {
+                    write_pool.submit([tx, ln, at, out_fd, &write_failed, &set_code] {
                         uint64_t done = 0;
                         while (done < ln) {
                             ssize_t r = pwrite(out_fd, tx + done, ln - done, at + (off_t)done);
                             if (r <= 0) {
                                 write_failed.store(true);
+                                set_code(11);  // binner.rs:136-139: the producer and the workers stop at once
                                 break;
                             }
                             done += (uint64_t)r;
@@ -769,6 +806,9 @@ int main(int argc, char** argv) {
                 }
             }
             for (unsigned k = 0; k < parts; k++) mtsv_free(text[k]);
+            // at most about two batches of text wait for the disk: the file stays a prefix of the results up to the
+            // writes in flight (resume reads its last line), and formatted text does not pile up behind a slow disk
+            write_pool.wait_below(2 * (size_t)host_threads + 1);
             pool.put(std::move(w->rb));
             if (!ok) continue;
             total += n_reads;

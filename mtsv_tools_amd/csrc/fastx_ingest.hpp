@@ -15,8 +15,11 @@
 #include <sys/stat.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
+#include <cstdlib>
+#include <new>
 #include <deque>
 #include <cstdint>
 #include <cstring>
@@ -31,8 +34,89 @@
 
 namespace mtsv_ingest {
 
+// Where the bases of a block live.  mtsv-binner points these at mtsv_host_alloc / mtsv_host_free, so that a parsed block
+// is page-locked memory the GPU's copy engine reads in place (no staging copy); elsewhere they stay malloc / free.
+struct ByteAlloc {
+    void* (*alloc)(size_t) = nullptr;
+    void (*release)(void*) = nullptr;
+};
+inline ByteAlloc& byte_alloc() {
+    static ByteAlloc a;
+    return a;
+}
+
+// the part of std::vector<uint8_t> the parsers use, on memory from byte_alloc() (malloc when that is unset or fails)
+class ByteBuf {
+   public:
+    ByteBuf() = default;
+    ByteBuf(const ByteBuf&) = delete;
+    ByteBuf& operator=(const ByteBuf&) = delete;
+    ByteBuf(ByteBuf&& o) noexcept { swap(o); }
+    ByteBuf& operator=(ByteBuf&& o) noexcept {
+        swap(o);
+        return *this;
+    }
+    ~ByteBuf() { drop(); }
+    void swap(ByteBuf& o) noexcept {
+        std::swap(p_, o.p_);
+        std::swap(n_, o.n_);
+        std::swap(cap_, o.cap_);
+        std::swap(pinned_, o.pinned_);
+    }
+    uint8_t* data() { return p_; }
+    const uint8_t* data() const { return p_; }
+    uint64_t size() const { return n_; }
+    const uint8_t* begin() const { return p_; }
+    const uint8_t* end() const { return p_ + n_; }
+    void clear() { n_ = 0; }
+    void reserve(uint64_t c) {
+        if (c <= cap_) return;
+        c = std::max<uint64_t>(c, cap_ + cap_ / 2);
+        uint8_t* q = nullptr;
+        bool pin = false;
+        if (byte_alloc().alloc) {
+            q = (uint8_t*)byte_alloc().alloc(c);
+            pin = q != nullptr;
+        }
+        if (!q) q = (uint8_t*)malloc(c);
+        if (!q) throw std::bad_alloc();
+        if (n_) memcpy(q, p_, n_);
+        const uint64_t keep = n_;
+        drop();
+        p_ = q;
+        n_ = keep;
+        cap_ = c;
+        pinned_ = pin;
+    }
+    // append [a, b) (the only insert position the parsers use is end())
+    void insert(const uint8_t* /*at_end*/, const uint8_t* a, const uint8_t* b) {
+        const uint64_t len = (uint64_t)(b - a);
+        if (n_ + len > cap_) reserve(n_ + len);
+        memcpy(p_ + n_, a, len);
+        n_ += len;
+    }
+    void assign(const uint8_t* a, const uint8_t* b) {
+        n_ = 0;
+        insert(nullptr, a, b);
+    }
+
+   private:
+    void drop() {
+        if (p_) {
+            if (pinned_) byte_alloc().release(p_);
+            else free(p_);
+        }
+        p_ = nullptr;
+        n_ = cap_ = 0;
+        pinned_ = false;
+    }
+    uint8_t* p_ = nullptr;
+    uint64_t n_ = 0, cap_ = 0;
+    bool pinned_ = false;
+};
+
 struct ReadBlock {
-    std::vector<uint8_t> bases;
+    ByteBuf bases;
     std::vector<uint64_t> off{0};     // n + 1 offsets into bases
     std::string ids;                  // NUL-terminated ids, back to back
     std::vector<uint64_t> id_off{0};  // n + 1 offsets into ids

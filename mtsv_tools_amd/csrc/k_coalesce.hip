@@ -654,7 +654,11 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     uint32_t* wl_count = reinterpret_cast<uint32_t*>(counters + 1);
     uint32_t* heavy_count = wl_count + 1;
     unsigned long long* n_cand_total = reinterpret_cast<unsigned long long*>(counters + 3);
-    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(n_strands, 16), 256 * 8));  // 4 strands per wavefront pass
+    // Grids follow the work on passes of a few hundred thousand reads: a workgroup costs ~0.1 us to dispatch whether it
+    // finds work or not, and the kernels of the other lanes wait for the same dispatcher (a host batch of 10 M reads in
+    // ranges of 0.3 - 1 M: 39.7 -> 38.8 ms).  Every kernel here strides over its list; a wavefront takes 64 strands per
+    // trip, at least four trips before the grid grows, but never fewer than 256 workgroups (short lists are latency-bound).
+    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(std::min<uint32_t>(cdiv(n_strands, 16), std::max<uint32_t>(cdiv(n_strands, 4 * 256), 256)), 256 * 8));
     CoalesceArgs c;
     c.read_off = read_off;
     c.r0 = r0;
@@ -673,7 +677,7 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     c.counters = counters;
     hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, c);
     // the list of longer strands is short (device-side count): a modest grid of wavefronts walks it
-    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 1024)), dim3(256), 0, s, ix, c);
+    hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 2048, std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 128)), 1024)), dim3(256), 0, s, ix, c);
     HeavyArgs a;
     a.read_off = read_off;
     a.r0 = r0;

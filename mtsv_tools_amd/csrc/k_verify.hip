@@ -1037,8 +1037,9 @@ __global__ __launch_bounds__(256, R > 10 ? 3 : (TOP ? kSwTopOcc : kSwOcc)) void 
     if (lane == 0 && v64) {
         atomicAdd((unsigned long long*)a.counters + kCtrVerified, v64);
         atomicAdd((unsigned long long*)a.counters + kCtrWindowBytes, w64);
-        if (s64) atomicAdd((unsigned long long*)a.counters + kCtrSwCellPairs, s64 * R);  // cell pairs swept (one packed 7-instruction recurrence each)
     }
+    // cell pairs swept (one packed 7-instruction recurrence each); also when every candidate came counted from k_sw_diag
+    if (lane == 0 && s64) atomicAdd((unsigned long long*)a.counters + kCtrSwCellPairs, s64 * R);
 }
 
 
@@ -1464,7 +1465,13 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             }
             const uint32_t Wn = c.y - c.x;
             int score = (int)L, best = (int)L;  // D[L][0] = L
-            uint4 nxt4 = Wn ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 0) : make_uint4(0, 0, 0, 0);
+            // The window's columns arrive 16 at a time, three fetches ahead of the recurrence: a lane's window is at a
+            // random place of a multi-GB text (a TLB miss and an HBM miss per fetch), and a wavefront that is alone on its
+            // SIMD -- every short work list -- has nothing else to cover them with.
+            const uint4 none = make_uint4(0, 0, 0, 0);
+            uint4 q0 = Wn ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 0) : none;
+            uint4 q1 = Wn > 16 ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 16) : none;
+            uint4 q2 = Wn > 32 ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 32) : none;
             const uint32_t* lane_tab = &eq_tab[0][0][tid];
             uint32_t j0 = 0;
             for (; j0 < Wn; j0 += 16) {
@@ -1472,8 +1479,10 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     if (best <= (int)ED) break;
                     if (best > 2 * (int)ED && score - (int)(Wn - j0) > 2 * (int)ED) break;
                 }
-                const uint4 cur = nxt4;
-                if (j0 + 16 < Wn) nxt4 = fetch_cols<BOUND>(ix, c.x, c.y, strand, j0 + 16);  // prefetch the next 16 columns
+                const uint4 cur = q0;
+                q0 = q1;
+                q1 = q2;
+                if (j0 + 48 < Wn) q2 = fetch_cols<BOUND>(ix, c.x, c.y, strand, j0 + 48);
                 const uint32_t lim = min(16u, Wn - j0);
 #pragma unroll
                 for (int jj = 0; jj < 16; jj++) {
@@ -1674,7 +1683,10 @@ void launch_evaluate_tiled(hipStream_t s, const DevIndexView& ix, const EvalArgs
     hipLaunchKernelGGL((k_evaluate<16, true, 16, true>), dim3(blocks), dim3(256), 0, s, ix, a);
 }
 
-void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items, uint32_t max_len, bool diag, bool top) {
+void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, uint64_t max_items_, uint32_t max_len, bool diag, bool top, bool sparse) {
+    // sparse: the work list is what the edit-distance bound left undecided -- a fraction of a percent of the seed hits
+    // max_items_ counts; a small grid (workgroups cost ~0.1 us each to dispatch, and these hold 40 KB of LDS)
+    const uint64_t max_items = sparse ? std::max<uint64_t>(max_items_ / 64, 1024) : max_items_;
     // persistent 16-lane groups, two candidates per group: one resident generation of blocks pulls the worklist
     EvalArgs a = a_;
     a.maxc = rank_bound(a.max_candidates);
@@ -1714,7 +1726,8 @@ void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_, 
 
 void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
                     uint32_t* sweep_list, uint32_t sweep_slot) {
-    const uint32_t grid = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 16), 256 * 8));  // 16 groups per workgroup
+    // 16 groups per workgroup, a candidate per group and trip; max_items counts seed hits, about four per candidate
+    const uint32_t grid = std::max<uint32_t>(16, std::min<uint32_t>(cdiv(max_items, 16 * 32), 256 * 6));
     if (max_len <= 128) hipLaunchKernelGGL(k_sw_diag<2>, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
     else if (max_len <= 192) hipLaunchKernelGGL(k_sw_diag<3>, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
     else hipLaunchKernelGGL(k_sw_diag<4>, dim3(grid), dim3(256), 0, s, ix, a, sweep_list, sweep_slot);
@@ -1724,7 +1737,10 @@ void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_
                        int mode) {
     EvalArgs a = a_;
     a.maxc = rank_bound(a.max_candidates);
-    uint32_t blocks = std::max<uint32_t>(1, std::min<uint32_t>(cdiv(max_items, 256), 256 * 8));
+    // max_items bounds the work list from far above (seed hits, not candidates); a grid of one resident generation at
+    // most, and smaller when the list is short: workgroups cost ~0.1 us each to dispatch, with work or without, and
+    // the lists are claimed 64 candidates at a time whatever the grid
+    uint32_t blocks = std::max<uint32_t>(16, std::min<uint32_t>(cdiv(max_items, 4096), 256 * 5));
     uint32_t W = (max_len + 31) / 32;
 #define MYERS_CASE(WW)                                                                                   \
     do {                                                                                                 \

@@ -125,8 +125,9 @@ void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a,
 // diag = false: without the lower bounds on the seed diagonal (every candidate that is not hopeless is swept)
 // top = true: the sweep on the top half of the read rows (k_sw_pairs<R/2, false, TOP>): refutes or passes what those rows
 // decide, appends the rest to a.und_list (count in the low word of counter slot a.und_slot), flagged, for a second launch
+// sparse = true: the work list holds a small fraction of max_items (what the edit-distance bound left): a small grid
 void launch_sw_pairs(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,
-                     bool diag = true, bool top = false);
+                     bool diag = true, bool top = false, bool sparse = false);
 // the prefilter's lower bounds alone, a lane per work item: decided candidates go to a.pass_list (count in kCtrPassCount),
 // the others to sweep_list (count in the low word of counter slot sweep_slot), flagged, for launch_sw_pairs
 void launch_sw_diag(hipStream_t s, const DevIndexView& ix, const EvalArgs& a, uint64_t max_items, uint32_t max_len,

@@ -174,3 +174,36 @@ def test_config4_chunks_one_per_device_entry(tmp_path):
     assert_same_hits(sel, want)
     for ix in chunks:
         ix.close()
+
+
+def test_host_batch_beyond_4_gib_of_bases():
+    """configs[3] hands one GPU 12.5 M reads of a 100 M-read node batch; the library takes host batches of any size: the
+    reads stream through input segments of at most 3 GiB (offsets inside a segment are 32-bit), two arenas taking turns.
+    30 M x 150 bp reads = 4.5 GB of bases in ordinary (pageable) memory against the "1 GB" index: the first reads and
+    reads beyond the 4 GiB mark against the oracle, and the part beyond the first segment against a call of its own."""
+    path = _index("config1")
+    ix = M.MGIndex.load(path)
+    ix.to_device(0)
+    L, part = 150, 10_000_000
+    bases = np.concatenate([M.synth_reads(ix, seed=4000 + k, n_reads=part, read_len=L)[0] for k in range(3)])
+    n_reads = 3 * part
+    assert len(bases) > (1 << 32)
+    off = np.arange(n_reads + 1, dtype=np.uint64) * L
+    whole = ix.bin_batch(bases, off, device=0)
+    assert len(whole) > 0.8 * n_reads and int(whole["read"].max()) > 29_900_000
+    orc = O.Index.read(path)
+    ns = 50_000
+    want, _ = orc.bin_batch(bases[: ns * L], off[: ns + 1], threads=min(16, os.cpu_count() or 8))
+    assert_same_hits(whole[whole["read"] < ns], want)
+    first = 29_000_000                                    # byte 4.35e9: beyond 2^32
+    tail_b, tail_o = bases[first * L: (first + ns) * L], off[: ns + 1]
+    want, _ = orc.bin_batch(tail_b, tail_o, threads=min(16, os.cpu_count() or 8))
+    sel = whole[(whole["read"] >= first) & (whole["read"] < first + ns)].copy()
+    sel["read"] -= first
+    assert_same_hits(sel, want)
+    del orc
+    h = 21_000_000                                        # inside the second segment
+    second = ix.bin_batch(bases[h * L:], off[h:] - off[h], device=0)
+    second["read"] += h
+    assert_same_hits(second, whole[whole["read"] >= h])
+    ix.close()
