@@ -458,6 +458,10 @@ int main(int argc, char** argv) {
                 ReadBlock& blk = *blk_owner;
                 auto r = use_gz ? gzpar.next(blk, &irregular) : par.next(blk, &irregular);
                 if (r == mtsv_ingest::ParallelFastx::END) break;
+                if (r == mtsv_ingest::ParallelFastx::CORRUPT) {  // records of a member whose CRC-32 then failed have been handed out
+                    rd.fail("corrupt gzip data (CRC mismatch)");
+                    return false;
+                }
                 if (r == mtsv_ingest::ParallelFastx::IRREGULAR) {
                     logmsg("DEBUG", std::string(use_gz ? "gzip input" : "input") + " is not plain 4-line FASTQ / FASTA (or not decodable in parallel) at byte " + std::to_string(irregular) + "; continuing with the serial reader");
                     if (gzseek(rd.in.f, (z_off_t)irregular, SEEK_SET) < 0) {

@@ -146,7 +146,8 @@ struct ReadBlock {
 
 class ParallelFastx {
    public:
-    enum Result { BLOCK = 0, END = 1, IRREGULAR = 2 };
+    // CORRUPT: the gzip data decoded but a member's CRC-32 / length did not match after records of it had been handed out
+    enum Result { BLOCK = 0, END = 1, IRREGULAR = 2, CORRUPT = 3 };
 
     ~ParallelFastx() { close(); }
 
@@ -458,9 +459,10 @@ class GzFastx {
             if (!done_.count(consumed_)) {
                 if (failed_at_ != UINT64_MAX) {  // the inflater gave up: everything before failed_at_ has been delivered
                     *irregular_offset = failed_at_;
+                    const bool corrupt = corrupt_;
                     lk.unlock();
                     stop();
-                    return ParallelFastx::IRREGULAR;
+                    return corrupt ? ParallelFastx::CORRUPT : ParallelFastx::IRREGULAR;
                 }
                 return ParallelFastx::END;
             }
@@ -544,7 +546,17 @@ class GzFastx {
                 stopping = stop_;
             }
             if (stopping) return finish(UINT64_MAX);  // (finish takes the mutex itself)
-            if (!gz_.next_round(pieces)) return finish(carry_off);  // nothing at or after carry_off has been handed out
+            if (!gz_.next_round(pieces)) {
+                // "Cannot decode in parallel" (no entry point, a header the decoder does not take): the serial reader takes
+                // over at carry_off -- nothing at or after it has been handed out.  A CRC-32 / length mismatch is
+                // another matter: a member is checked at its end, after its earlier rounds went to the GPU, so records
+                // already delivered are suspect and the run must fail (the reference's reader fails such a file too).
+                if (gz_.crc_mismatch() && !first) {
+                    std::lock_guard<std::mutex> lk(mu_);
+                    corrupt_ = true;
+                }
+                return finish(carry_off);
+            }
             for (auto& piece : pieces) {
                 if (piece.empty()) continue;
                 Buf pb = std::make_shared<std::vector<uint8_t>>(std::move(piece));
@@ -556,11 +568,9 @@ class GzFastx {
                     uint64_t b0 = ParallelFastx::find_boundary_in(d, n, fastq_, 1);
                     if (b0 == UINT64_MAX) {  // no boundary in the whole piece: keep collecting
                         carry.insert(carry.end(), d, d + n);
-                        if (carry.size() > (1ull << 30)) {  // a gigabyte without a record start: not FASTA / FASTQ
-                            Buf cb = std::make_shared<std::vector<uint8_t>>(std::move(carry));
-                            if (!submit(cb, cb->data(), cb->size(), carry_off, first, false)) return finish(UINT64_MAX);
-                            return finish(UINT64_MAX);
-                        }
+                        // a gigabyte without a record start (one FASTA record of that size, or not FASTA / FASTQ at all):
+                        // the serial reader continues at carry_off and gives the reference's result or error
+                        if (carry.size() > (1ull << 30)) return finish(carry_off);
                         continue;
                     }
                     Buf sb = std::make_shared<std::vector<uint8_t>>(std::move(carry));
@@ -646,7 +656,7 @@ class GzFastx {
     std::deque<std::pair<uint64_t, std::unique_ptr<Task>>> queue_;
     std::map<uint64_t, std::unique_ptr<Task>> done_;
     uint64_t n_tasks_ = 0, consumed_ = 0, failed_at_ = UINT64_MAX;
-    bool produced_all_ = false, stop_ = false;
+    bool produced_all_ = false, stop_ = false, corrupt_ = false;
 };
 
 }  // namespace mtsv_ingest

@@ -588,6 +588,7 @@ class ParallelGunzip {
         fd_ = -1;
     }
     const std::string& error() const { return err_; }
+    bool crc_mismatch() const { return crc_mismatch_; }  // the last failure: data decoded, a member's CRC-32 / ISIZE did not match
     bool at_end() const { return done_; }
 
     // Decompress the next round; the pieces come back in file order.  false + error() on failure.
@@ -743,7 +744,10 @@ class ParallelGunzip {
                 crc_ = (uint32_t)crc32_combine(crc_, crcs[k][m].first, (z_off_t)crcs[k][m].second);
                 member_len_ += crcs[k][m].second;
                 if (m < c.members.size()) {
-                    if (crc_ != c.members[m].crc || (uint32_t)member_len_ != c.members[m].isize) return fail("CRC mismatch: corrupt gzip data");
+                    if (crc_ != c.members[m].crc || (uint32_t)member_len_ != c.members[m].isize) {
+                        crc_mismatch_ = true;
+                        return fail("CRC mismatch: corrupt gzip data");
+                    }
                     crc_ = (uint32_t)crc32(0L, Z_NULL, 0);
                     member_len_ = 0;
                 }
@@ -901,6 +905,7 @@ class ParallelGunzip {
     uint32_t crc_ = 0;
     bool done_ = false;
     std::string err_;
+    bool crc_mismatch_ = false;
 };
 
 }  // namespace mtsv_pgzip

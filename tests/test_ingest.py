@@ -238,7 +238,12 @@ def test_gzip_input_irregular_and_corrupt_files(tmp_path):
     for k in range(len(bad) // 3, len(bad) // 3 + 40):
         bad[k] ^= 0x5a
     (tmp_path / "bad.fq.gz").write_bytes(bytes(bad))
-    for name in ("trunc.fq.gz", "bad.fq.gz"):
+    # every deflate block intact, only the member's CRC-32 in the trailer wrong: the parallel inflater checks a member at its
+    # end, after its earlier rounds have been handed on -- that must fail the run like the serial stream does, not resume
+    crc = bytearray(good)
+    crc[-8] ^= 0x01
+    (tmp_path / "crc.fq.gz").write_bytes(bytes(crc))
+    for name in ("trunc.fq.gz", "bad.fq.gz", "crc.fq.gz"):
         s = parse_gz(tmp_path / name, True, serial=True)
         g = parse_gz(tmp_path / name, True, chunk=65536)
         assert s[0] == 12 and g[0] == 12, (name, s, g)
