@@ -407,11 +407,28 @@ int main(int argc, char** argv) {
             b->clear();
             return b;
         }
+        size_t keep = 8;
         void put(std::unique_ptr<ReadBlock> b) {
             std::lock_guard<std::mutex> lk(mu);
-            if (free.size() < 8) free.push_back(std::move(b));
+            if (free.size() < keep) free.push_back(std::move(b));
+        }
+        // a stock of blocks whose (page-locked) base buffers exist before the first query: creating one costs
+        // milliseconds per block, which the first second of a run would otherwise spend in its parser threads
+        void stock(size_t n, uint64_t base_bytes) {
+            keep = std::max(keep, n);
+            std::vector<std::thread> th;
+            std::vector<std::unique_ptr<ReadBlock>> made(n);
+            for (size_t k = 0; k < n; k++)
+                th.emplace_back([&made, k, base_bytes] {
+                    made[k] = std::make_unique<ReadBlock>();
+                    made[k]->bases.reserve(base_bytes);
+                });
+            for (auto& t : th) t.join();
+            std::lock_guard<std::mutex> lk(mu);
+            for (auto& b : made) free.push_back(std::move(b));
         }
     } pool;
+    uint64_t plain_block_bytes = 0;  // set by block_bytes_for(): the ingest block size of plain input
     auto produce = [&](uint64_t batch_reads, const std::function<bool(std::unique_ptr<ReadBlock>)>& emit) -> bool {
         auto w = pool.get();
         uint64_t skipped = 0;
@@ -430,6 +447,7 @@ int main(int argc, char** argv) {
         // engine reads in place, and the producer thread hands it on without touching the bases again.
         uint64_t ingest_block = 16ull << 20;
         if (getenv("MTSV_INGEST_BLOCK")) ingest_block = strtoull(getenv("MTSV_INGEST_BLOCK"), nullptr, 10);
+        else if (plain_block_bytes) ingest_block = plain_block_bytes;
         else if (FILE* hf = fopen(input.c_str(), "rb")) {
             std::vector<char> head(256 << 10);
             const size_t got = fread(head.data(), 1, head.size(), hf);
@@ -444,8 +462,15 @@ int main(int argc, char** argv) {
                     for (size_t i = 0; i < got; i++) recs += head[i] == '>' && (i == 0 || head[i - 1] == '\n');
                 }
             }
-            if (recs >= 8) ingest_block = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)got / (double)recs * (double)batch_reads), 4ull << 20), 256ull << 20);
+            // (capped at 96 MiB: a parser thread is slower per byte on larger blocks -- 1 Mi-read blocks of 335 MB parsed at a
+            //  third of the rate -- and batches beyond that are put together from several blocks as before)
+            if (recs >= 8) ingest_block = std::min<uint64_t>(std::max<uint64_t>((uint64_t)((double)got / (double)recs * (double)batch_reads), 4ull << 20), 96ull << 20);
         }
+        plain_block_bytes = ingest_block;
+        par.prepare = [&pool](ReadBlock& b) {
+            auto stocked = pool.get();
+            std::swap(b, *stocked);
+        };
         bool serial_from_start = getenv("MTSV_SERIAL_INGEST") != nullptr || !par.open(input, fastq, host_threads, ingest_block);
         if (serial_from_start && !getenv("MTSV_SERIAL_INGEST") && !getenv("MTSV_SERIAL_GZIP") && gzpar.open(input, fastq, gz_threads, ingest_block)) {
             use_gz = true;
@@ -453,7 +478,7 @@ int main(int argc, char** argv) {
         }
         if (!serial_from_start) {
             auto blk_owner = pool.get();
-            uint64_t irregular = 0;
+            uint64_t irregular = 0, direct_emitted = 0;
             for (;;) {
                 ReadBlock& blk = *blk_owner;
                 auto r = use_gz ? gzpar.next(blk, &irregular) : par.next(blk, &irregular);
@@ -477,7 +502,11 @@ int main(int argc, char** argv) {
                     skipped += from;
                 }
                 // a block of about a batch, nothing pending: the block is the batch
-                if (from == 0 && w->n() == 0 && blk.n() && blk.n() <= batch_reads + batch_reads / 2 && blk.bases.size() < (1ull << 30)) {
+                // (smaller blocks are collected into a batch -- except the first ones of the file, which the parser cuts
+                //  short on purpose so that the GPU has work early)
+                if (from == 0 && w->n() == 0 && blk.n() && blk.n() <= batch_reads + batch_reads / 2 && blk.bases.size() < (1ull << 30) &&
+                    (2 * blk.n() >= batch_reads || direct_emitted < 4)) {
+                    direct_emitted++;
                     if (!emit(std::move(blk_owner))) return true;
                     blk_owner = pool.get();
                     continue;
@@ -599,11 +628,35 @@ int main(int argc, char** argv) {
             }
     }
     // parsed blocks land in page-locked memory from here on: the GPU copies them from where the parser put them
-    mtsv_ingest::byte_alloc().alloc = [](size_t n) { return mtsv_host_alloc(n); };
-    mtsv_ingest::byte_alloc().release = [](void* q) { mtsv_host_free(q); };
+    // the workers' workspaces (one index): part of the device set-up, like making the index resident
+    std::vector<mtsv_batch*> ws_ready(chunked ? 0 : a.devices.size(), nullptr);
+    for (size_t wk = 0; wk < ws_ready.size(); wk++)
+        if (mtsv_batch_create(idx[0], a.devices[wk], mtsv_bin_batch_workspace_reads(a.batch_reads), 1 << 22, 0, &ws_ready[wk]) != MTSV_OK) {
+            logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
+            return 2;
+        }
+    // (batches too large for one parser block are put together from several blocks by appending: those stay in ordinary
+    //  memory -- growing a page-locked buffer means allocating another one -- and are staged by the library)
+    if (!getenv("MTSV_CLI_PAGEABLE") && (uint64_t)a.batch_reads * 320 <= (128ull << 20)) {
+        mtsv_ingest::byte_alloc().alloc = [](size_t n) { return mtsv_host_alloc(n); };
+        mtsv_ingest::byte_alloc().release = [](void* q) { mtsv_host_free(q); };
+        // stock: the parser's window of blocks plus what sits in the queues and with the workers
+        if (const char* e = getenv("MTSV_INGEST_BLOCK")) plain_block_bytes = strtoull(e, nullptr, 10);
+        const uint64_t est = plain_block_bytes ? plain_block_bytes : (uint64_t)a.batch_reads * 320;
+        pool.stock(std::min<size_t>(2 * host_threads + 2 + 3 * (a.devices.size() + 1), 64), std::min<uint64_t>(est / 2 + (1 << 20), 512ull << 20));
+    }
     logmsg("INFO", "Beginning queries.");
     struct timespec w0;
     clock_gettime(CLOCK_MONOTONIC, &w0);
+    // MTSV_CLI_TIMING=1: where the stages of the command line spend their time (seconds, summed per stage)
+    const bool cli_timing = getenv("MTSV_CLI_TIMING") != nullptr;
+    auto now = [] {
+        struct timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return t.tv_sec + t.tv_nsec * 1e-9;
+    };
+    std::atomic<uint64_t> t_ingest_wait{0}, t_push_wait{0}, t_gpu{0}, t_gpu_wait{0}, t_fmt{0}, t_done_wait{0}, t_write_wait{0};
+    auto acc = [](std::atomic<uint64_t>& a, double s) { a.fetch_add((uint64_t)(s * 1e6)); };
 
     // Overlapped stages (the reference overlaps producer / workers / joiner the same way,
     // vendor/cue/src/lib.rs:45-105): the producer parses FASTX into numbered batches, GPU workers (one per
@@ -659,12 +712,17 @@ int main(int argc, char** argv) {
 
     uint64_t n_batches = 0;
     std::thread reader([&] {
+        double t_last = now();
         bool ok = produce(a.batch_reads, [&](std::unique_ptr<ReadBlock> rb) {
             if (failed()) return false;
             auto w = std::make_unique<Work>();
             w->rb = std::move(rb);
             w->seq = n_batches++;
+            const double t_a = now();
+            acc(t_ingest_wait, t_a - t_last);  // producing this batch (mostly: waiting for the parser threads)
             parsed.push(std::move(w));
+            t_last = now();
+            acc(t_push_wait, t_last - t_a);    // waiting for room in the queue to the GPU workers
             return true;
         });
         if (!ok) {
@@ -745,7 +803,9 @@ int main(int argc, char** argv) {
                     break;
                 }
             if (!w) {
+                const double t_a = now();
                 w = done.pop();
+                acc(t_done_wait, now() - t_a);
                 if (!w) break;
                 if (w->seq != next_seq) {
                     held.push_back(std::move(w));
@@ -753,6 +813,7 @@ int main(int argc, char** argv) {
                 }
             }
             next_seq++;
+            const double t_f0 = now();
             // write_assignments over slices of the batch's hits (cut between reads), one thread each
             const uint64_t n_reads = w->rb->n();
             const unsigned parts = w->n_hits >= (1u << 16) ? host_threads : 1;
@@ -780,6 +841,7 @@ int main(int argc, char** argv) {
                 fmt(0);
             }
             mtsv_hits_free(w->hits);
+            acc(t_fmt, now() - t_f0);
             bool ok = true;
             for (unsigned k = 0; k < parts; k++)
                 if (rc[k] != MTSV_OK) {
@@ -812,7 +874,11 @@ int main(int argc, char** argv) {
             for (unsigned k = 0; k < parts; k++) mtsv_free(text[k]);
             // at most about two batches of text wait for the disk: the file stays a prefix of the results up to the
             // writes in flight (resume reads its last line), and formatted text does not pile up behind a slow disk
-            write_pool.wait_below(2 * (size_t)host_threads + 1);
+            {
+                const double t_a = now();
+                write_pool.wait_below(2 * (size_t)host_threads + 1);
+                acc(t_write_wait, now() - t_a);
+            }
             pool.put(std::move(w->rb));
             if (!ok) continue;
             total += n_reads;
@@ -826,22 +892,21 @@ int main(int argc, char** argv) {
     });
 
     auto gpu_worker = [&](size_t wk) {
-        mtsv_batch* ws = nullptr;  // one index: this worker's own workspace on its device
-        while (auto w = parsed.pop()) {
+        mtsv_batch* ws = chunked ? nullptr : ws_ready[wk];  // one index: this worker's own workspace on its device
+        for (;;) {
+            const double t_p = now();
+            auto w = parsed.pop();
+            acc(t_gpu_wait, now() - t_p);
+            if (!w) break;
             if (failed()) continue;  // drain
+            const double t_g = now();
             int rc;
             if (chunked) {
                 rc = mtsv_bin_batch_chunks(idx.data(), chunk_dev.data(), (int)idx.size(), w->rb->bases.data(), w->rb->off.data(), w->rb->n(), &p,
                                            &w->hits, &w->n_hits);
             } else {
-                const uint64_t nb = w->rb->bases.size(), nr = w->rb->n();
-                if (!ws) {
-                    const uint64_t ws_reads = mtsv_bin_batch_workspace_reads(a.batch_reads);
-                    // room for reads a third longer than this batch's before slices are cut by bases
-                    const uint64_t ws_bases = std::max<uint64_t>(1 << 22, (uint64_t)((double)nb / (double)std::max<uint64_t>(nr, 1) * (double)ws_reads * 1.33));
-                    rc = mtsv_batch_create(idx[0], a.devices[wk], ws_reads, ws_bases, 0, &ws);
-                } else
-                    rc = MTSV_OK;
+                const uint64_t nr = w->rb->n();
+                rc = MTSV_OK;
                 if (rc == MTSV_OK) rc = mtsv_batch_run_host(ws, w->rb->bases.data(), w->rb->off.data(), nr, &p);
                 if (rc == MTSV_OK) rc = mtsv_batch_download(ws, &w->hits, &w->n_hits);
             }
@@ -850,6 +915,7 @@ int main(int argc, char** argv) {
                 set_code(2);
                 continue;
             }
+            acc(t_gpu, now() - t_g);
             done.push(std::move(w));
         }
         if (ws) mtsv_batch_free(ws);
@@ -874,6 +940,11 @@ int main(int argc, char** argv) {
     snprintf(msg, sizeof msg, "All worker and result consumer threads terminated. Took %.3f seconds.",
              (w1.tv_sec - w0.tv_sec) + (w1.tv_nsec - w0.tv_nsec) * 1e-9);
     logmsg("INFO", msg);
+    if (cli_timing)
+        fprintf(stderr, "[cli timing] batches %llu; reader: producing %.3f s, queue full %.3f s; gpu workers: in the library %.3f s, waiting for batches %.3f s; "
+                        "writer: formatting %.3f s, waiting for hits %.3f s, waiting for the disk %.3f s\n",
+                (unsigned long long)n_batches, t_ingest_wait.load() * 1e-6, t_push_wait.load() * 1e-6, t_gpu.load() * 1e-6, t_gpu_wait.load() * 1e-6,
+                t_fmt.load() * 1e-6, t_done_wait.load() * 1e-6, t_write_wait.load() * 1e-6);
     for (auto* ix : idx) mtsv_index_free(ix);
     return 0;
 }

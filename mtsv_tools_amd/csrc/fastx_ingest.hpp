@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <new>
 #include <deque>
+#include <functional>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -146,6 +147,10 @@ struct ReadBlock {
 
 class ParallelFastx {
    public:
+    // called on every block object the parser threads create themselves (the others arrive through next(), in exchange for
+    // the parsed ones): the caller may swap in a block whose buffers are already allocated
+    std::function<void(ReadBlock&)> prepare;
+
     // CORRUPT: the gzip data decoded but a member's CRC-32 / length did not match after records of it had been handed out
     enum Result { BLOCK = 0, END = 1, IRREGULAR = 2, CORRUPT = 3 };
 
@@ -174,10 +179,21 @@ class ParallelFastx {
             return false;
         }
         // block boundaries
+        // (blocks of more than 32 MiB start with an eighth, an eighth, a quarter and a half of a block: the consumer has
+        //  its first records after an eighth of the time a whole block takes to parse)
         bounds_.push_back(0);
-        for (uint64_t t = block_bytes; t < size_; t += block_bytes) {
-            uint64_t b = find_boundary(std::max(t, bounds_.back() + 1));
-            if (b != UINT64_MAX && b > bounds_.back() && b < size_) bounds_.push_back(b);
+        {
+            const uint64_t ramp[4] = {block_bytes / 8, block_bytes / 8, block_bytes / 4, block_bytes / 2};
+            uint64_t t = 0;
+            for (size_t k = 0;; k++) {
+                t += (block_bytes > (32ull << 20) && k < 4) ? std::max<uint64_t>(ramp[k], 1) : block_bytes;
+                if (t >= size_) break;
+                uint64_t b = find_boundary(std::max(t, bounds_.back() + 1));
+                if (b != UINT64_MAX && b > bounds_.back() && b < size_) {
+                    bounds_.push_back(b);
+                    t = std::max(t, b);
+                }
+            }
         }
         bounds_.push_back(size_);
         n_blocks_ = bounds_.size() - 1;
@@ -293,7 +309,10 @@ class ParallelFastx {
                     free_.pop_back();
                 }
             }
-            if (!p) p = std::make_unique<Parsed>();
+            if (!p) {
+                p = std::make_unique<Parsed>();
+                if (prepare) prepare(p->block);  // (a block with its storage already there, from the caller's stock)
+            }
             const uint64_t s = bounds_[k], len = bounds_[k + 1] - s;
             if (buf.size() < len) buf.resize(len);
             uint64_t got = 0;

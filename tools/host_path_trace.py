@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--workload", default="config2")
     ap.add_argument("--warm", type=int, default=3)
     ap.add_argument("--reads", type=int, default=0)
+    ap.add_argument("--verify-mode", type=int, default=0)
     ap.add_argument("--resident-sweep", default="", help="';'-separated settings 'K=V,K=V': the RESIDENT step (reads in HBM) under each")
     ap.add_argument("--sweep", default="", help="';'-separated settings, each 'K=V,K=V' (environment of a fresh workspace; "
                     "SLICE = workspace reads): prints the step times of each instead of tracing one")
@@ -48,7 +49,9 @@ def main():
 
     def workspace(slice_reads=0):
         slice_reads = slice_reads or int(os.environ.get("MTSV_BENCH_SLICE", 0)) or M.bin_batch_slice_reads(n_reads)
-        return M.Batch(ix, 0, min(n_reads, slice_reads), min(len(bases), slice_reads * (read_len + 8)))
+        b_ = M.Batch(ix, 0, min(n_reads, slice_reads), min(len(bases), slice_reads * (read_len + 8)))
+        b_.set_verify_mode(args.verify_mode)
+        return b_
 
     def step():
         t0 = time.perf_counter()
