@@ -252,6 +252,8 @@ void Batch::finish_lane() {
     launch_publish(stream, d_counters, h_counters, kCounters);
     HIP_CHECK(hipStreamSynchronize(stream));
     HIP_CHECK(hipEventElapsedTime(&stage_acc[7], ev[8], ev[9]));
+    if (getenv("MTSV_TRACE")) fprintf(stderr, "[lane] last pass: %llu strands of 13..64 seed hits (or more than 4 candidates) to k_coalesce_mid, %llu heavier ones\n",
+                                      (unsigned long long)(h_counters[15] & 0xffffffffull), (unsigned long long)(h_counters[1] >> 32));
     stats.sw_cell_pairs = h_counters[14];
     stats.sw_prefilter_ms = sw_ms_acc;
     stats.sw_sweep_ms = sweep_ms_acc;

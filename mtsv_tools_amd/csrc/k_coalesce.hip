@@ -339,175 +339,236 @@ __device__ inline uint32_t* co_heavy_count(const CoalesceArgs& a) { return reint
 __device__ inline uint32_t* co_mid_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 15); }
 __device__ inline unsigned long long* co_n_cand(const CoalesceArgs& a) { return reinterpret_cast<unsigned long long*>(a.counters + 3); }
 
+// A strand per LANE.  Most strands hold no seed hit at all (the other strand of a read, reads without an origin), a
+// chance hit or two, or the seven to ten hits of the read's own origin -- and the walk of index.rs:445-485 is sequential,
+// so sixteen lanes per strand (the previous arrangement) repeated one walk sixteen times: 1.8e9 vector and 1.4e9
+// scalar instructions for 10 M non-empty strands.  Here a lane sorts its strand's up to kLaneHits (reference, query)
+// keys in registers with a fixed comparator network, walks them (the bin of a hit is looked up only when the sorted
+// sites leave the current bin), keeps up to kLaneCands coalesced candidates in registers, ranks them by counting
+// (stable: num_seeds descending, index.rs:369) and links the same-TaxId chains.  Strands with more hits go to
+// k_coalesce_mid (up to 64) and k_coalesce_heavy; a strand whose hits coalesce into more than kLaneCands candidates is
+// rare (every candidate beyond the first is a separate chance window) and goes to k_coalesce_mid as well.
+// Everything a wavefront appends to a shared list -- work items, the strands it passes on -- is buffered in LDS and
+// appended with one atomic per few hundred entries: a returning atomic on one address completes at ~11 ns, and one per
+// 64 strands (312 k of them for 10 M reads) had been a floor of 3.4 ms under this kernel whatever its instructions.
+constexpr int kLaneHits = 12, kLaneCands = 4;
+constexpr uint32_t kPendCap = 768, kPendFlush = 512;  // work items a wavefront buffers in LDS; flushed with one atomic beyond kPendFlush
+constexpr uint32_t kMidCap = 256, kMidFlush = 192;    // strands for k_coalesce_mid, likewise
+constexpr uint32_t kHeavyCap = 128, kHeavyFlush = 64;  // ... and for k_coalesce_heavy
+
+// ascending comparator network for 12 keys (Batcher's odd-even merge sort of 16 with the comparators of the four padding
+// positions removed): 41 comparators
+#define MTSV_SORT12(CX)                                                                                                  \
+    CX(0, 1) CX(2, 3) CX(0, 2) CX(1, 3) CX(1, 2) CX(4, 5) CX(6, 7) CX(4, 6) CX(5, 7) CX(5, 6) CX(0, 4) CX(2, 6) CX(2, 4)  \
+    CX(1, 5) CX(3, 7) CX(3, 5) CX(1, 2) CX(3, 4) CX(5, 6) CX(8, 9) CX(10, 11) CX(8, 10) CX(9, 11) CX(9, 10) CX(0, 8)      \
+    CX(4, 8) CX(2, 10) CX(6, 10) CX(2, 4) CX(6, 8) CX(1, 9) CX(5, 9) CX(3, 11) CX(7, 11) CX(3, 5) CX(7, 9) CX(1, 2)       \
+    CX(3, 4) CX(5, 6) CX(7, 8) CX(9, 10)
+
 __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs a) {
-    __shared__ uint32_t pend_all[256 / kWave][kWave];
+    __shared__ uint32_t pend_all[256 / kWave][kPendCap];
+    __shared__ uint32_t mid_all[256 / kWave][kMidCap];
+    __shared__ uint32_t heavy_all[256 / kWave][kHeavyCap];
     uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
+    uint32_t* mid_buf = mid_all[threadIdx.x / kWave];
+    uint32_t* heavy_buf = heavy_all[threadIdx.x / kWave];
     const uint32_t lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
     const uint32_t n_waves = gridDim.x * blockDim.x / kWave;
-    uint32_t pend = 0;  // work items buffered in pend_buf (wave-uniform)
+    uint32_t pend = 0, n_mid = 0, n_heavy = 0;  // entries buffered in LDS (wave-uniform)
     unsigned long long cand_sum = 0, ver_sum = 0, win_sum = 0;
-    // A wavefront takes 64 consecutive strands at a time, one per lane, sorts them into classes -- empty (more
-    // than half of all strands: the other strand of a read, reads without an origin), 1..16 seed hits, longer --
-    // and then works through the 1..16-hit ones only, four at a time (one 16-lane group each).
-    for (uint32_t base64 = wave * kWave; base64 < a.n_strands; base64 += n_waves * kWave) {
-      const uint32_t my_rs = base64 + lane;
-      const bool my_valid = my_rs < a.n_strands;
-      const uint32_t my_o = my_valid ? a.strand_off[my_rs] : 0;
-      const uint32_t my_nh = my_valid ? a.strand_off[my_rs + 1] - my_o : 0;
-      if (my_valid && my_nh == 0) a.strand_ncand[my_rs] = 0;
-      {
-          const bool mid = my_nh > 16 && my_nh <= (uint32_t)kWave, heavy = my_nh > (uint32_t)kWave;
-          const unsigned long long bm = __ballot(mid), bh = __ballot(heavy);
-          if (bm) {  // front of the list: k_coalesce_mid
-              uint32_t b = 0;
-              if (lane == 0) b = atomicAdd(co_mid_count(a), (uint32_t)__popcll(bm));
-              b = __builtin_amdgcn_readfirstlane(b);
-              if (mid) a.heavy_list[b + __popcll(bm & ((1ull << lane) - 1))] = my_rs;
-          }
-          if (bh) {  // back of the list: k_coalesce_heavy
-              uint32_t b = 0;
-              if (lane == 0) b = atomicAdd(co_heavy_count(a), (uint32_t)__popcll(bh));
-              b = __builtin_amdgcn_readfirstlane(b);
-              if (heavy) a.heavy_list[a.n_strands - 1 - (b + __popcll(bh & ((1ull << lane) - 1)))] = my_rs;
-          }
-      }
-      unsigned long long small = __ballot(my_nh >= 1 && my_nh <= 16);
-      while (small) {
-        // the next four strands of this class, one per group (lane number inside the 64; 64 = none left)
-        uint32_t src = 64;
-        {
-            unsigned long long m = small;
-#pragma unroll
-            for (uint32_t g4 = 0; g4 < 4; g4++) {
-                const uint32_t s_g = m ? (uint32_t)__ffsll((long long)m) - 1 : 64u;
-                if (m) m &= m - 1;
-                if ((lane >> 4) == g4) src = s_g;
-            }
-            small = m;
-        }
-        const uint32_t gl = lane & 15, gbase = lane & 48;
-        const bool gvalid = src < 64;
-        const uint32_t grs = base64 + src;
-        const uint32_t go = (uint32_t)__shfl((int)my_o, (int)(src & 63)), gnh_raw = (uint32_t)__shfl((int)my_nh, (int)(src & 63));
-        const uint32_t gnh = gvalid ? gnh_raw : 0;
-        const bool big = false;
-        uint32_t maxnh = gnh;
-        maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 16));
-        maxnh = max(maxnh, (uint32_t)__shfl_xor((int)maxnh, 32));
-        maxnh = __builtin_amdgcn_readfirstlane(maxnh);
-        StrandGeom gg{0, 0, 1};
-        bool hopeless = false;  // group-uniform: k_thin's flag (see kHopeless)
-        if (gvalid && gnh) {
-            const uint32_t ns_raw = a.strand_nseeds[grs];
-            hopeless = (ns_raw & kHopeless) != 0;
-            gg = strand_geom(a.read_off, a.r0 + (grs >> 1), ns_raw);
-        }
-        uint64_t key = gl < gnh ? ((uint64_t)a.hit_ref[go + gl] << 32) | a.hit_q[go + gl] : ~0ull;
-        for (uint32_t k = 2; k <= 16; k <<= 1)  // bitonic sort inside the 16-lane group
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                uint64_t other = __shfl_xor(key, j);
-                bool up = (gl & k) == 0, lower = (gl & j) == 0;
-                key = (lower == up) ? min(key, other) : max(key, other);
-            }
-        uint32_t site = (uint32_t)(key >> 32), q = (uint32_t)key;
-        uint32_t b = 0, ws = 0, we = 0, btax = 0;
-        bool ok = false;
-        if (gl < gnh) {
-            b = min(find_bin(ix, site), ix.n_bins - 1);
-            DevBin bin = ix.bins[b];
-            btax = bin.tax_id;  // travels with the walk: no dependent reload of the candidate's bin
-            ok = candidate_window(site, q, bin, gg.L, gg.ED, &ws, &we);
-        }
-        Walk w{false, 0, 0, 0, 0};
-        uint32_t wtax = 0;
-        uint32_t gnc = 0, ms = 0, me = 0, mb = 0, mn = 0, mtax = 0;
-        for (uint32_t i = 0; i < maxnh; i++) {
-            const int src = (int)(gbase + i);
-            uint32_t wsi = (uint32_t)__shfl((int)ws, src), wei = (uint32_t)__shfl((int)we, src);
-            uint32_t bi = (uint32_t)__shfl((int)b, src), ti = (uint32_t)__shfl((int)btax, src);
-            bool oki = __shfl((int)ok, src) != 0;
-            if (i < gnh) {
-                bool merge = w.have && oki && bi == w.b && ((w.s <= wsi && wsi < w.e) || (w.s < wei && wei <= w.e));
-                if (merge) {
-                    w.s = min(w.s, wsi);
-                    w.e = max(w.e, wei);
-                    w.n++;
-                } else {
-                    if (w.have && w.n >= gg.min_seeds) {
-                        if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
-                        gnc++;
-                    }
-                    w.have = oki;
-                    w.s = wsi; w.e = wei; w.b = bi; w.n = 1;
-                    wtax = ti;
-                }
-            }
-        }
-        if (w.have && w.n >= gg.min_seeds) {
-            if (gl == gnc) { ms = w.s; me = w.e; mb = w.b; mn = w.n; mtax = wtax; }
-            gnc++;
-        }
-        uint32_t maxnc = gnc;
-        maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 16));
-        maxnc = max(maxnc, (uint32_t)__shfl_xor((int)maxnc, 32));
-        maxnc = __builtin_amdgcn_readfirstlane(maxnc);
-        const uint32_t tax = gl < gnc ? mtax : 0;
-        uint32_t rank = 0;
-        for (uint32_t j = 0; j < maxnc; j++) {
-            uint32_t nj = (uint32_t)__shfl((int)mn, (int)(gbase + j));
-            if (j < gnc) rank += (nj > mn) || (nj == mn && j < gl);
-        }
-        uint32_t nxt = 0xffffffffu;
-        bool first = gl < gnc;
-        for (uint32_t j = 0; j < maxnc; j++) {
-            uint32_t tj = (uint32_t)__shfl((int)tax, (int)(gbase + j)), rj = (uint32_t)__shfl((int)rank, (int)(gbase + j));
-            if (j < gnc) {
-                if (tj == tax && rj > rank && rj < nxt) nxt = rj;
-                if (tj == tax && rj < rank) first = false;
-            }
-        }
-        if (gl < gnc && !hopeless) {
-            a.cand[go + rank] = make_uint4(ms, me, mb, grs);
-            a.cand_next[go + rank] = nxt;
-            a.cand_status[go + rank] = 0;
-        }
-        // a hopeless strand: the reference prefilters each of its candidates (up to max_candidates) and none can
-        // pass; that work is accounted here and the strand leaves the pipeline (no candidates to resolve)
-        const int hw = row_sum16((hopeless && gl < gnc && rank < a.maxc) ? (int)(me - ms) : 0);
-        if (gvalid && gl == 0 && !big) a.strand_ncand[grs] = hopeless ? 0 : gnc;
-        if (gl == 0) {
-            cand_sum += gnc;
-            if (hopeless) {
-                ver_sum += min(gnc, a.maxc);
-                win_sum += (uint32_t)hw;
-            }
-        }
-        {
-            bool emit = first && rank < a.maxc && !hopeless;
-            unsigned long long em = __ballot(emit);
-            uint32_t m = __popcll(em);
-            if (pend + m > kWave) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
-                base = __builtin_amdgcn_readfirstlane(base);
-                wave_mem_sync();
-                if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
-                wave_mem_sync();
-                pend = 0;
-            }
-            if (emit) pend_buf[pend + __popcll(em & ((1ull << lane) - 1))] = go + rank;
-            pend += m;
-        }
-      }
-    }
-    if (pend) {
+    // (uniform values that are needed rarely live in vector registers: the kernel sits at the scalar register file's limit)
+    uint32_t maxc = a.maxc, r0 = a.r0;
+    asm volatile("" : "+v"(maxc), "+v"(r0));
+    auto flush_pend = [&]() {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(co_wl_count(a), pend);
         base = __builtin_amdgcn_readfirstlane(base);
         wave_mem_sync();
-        if (lane < pend) a.worklist[base + lane] = pend_buf[lane];
+        for (uint32_t i = lane; i < pend; i += kWave) a.worklist[base + i] = pend_buf[i];
+        wave_mem_sync();
+        pend = 0;
+    };
+    auto flush_mid = [&]() {  // front of the strand list: k_coalesce_mid
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(co_mid_count(a), n_mid);
+        base = __builtin_amdgcn_readfirstlane(base);
+        wave_mem_sync();
+        for (uint32_t i = lane; i < n_mid; i += kWave) a.heavy_list[base + i] = mid_buf[i];
+        wave_mem_sync();
+        n_mid = 0;
+    };
+    auto flush_heavy = [&]() {  // back of the strand list: k_coalesce_heavy
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(co_heavy_count(a), n_heavy);
+        base = __builtin_amdgcn_readfirstlane(base);
+        wave_mem_sync();
+        for (uint32_t i = lane; i < n_heavy; i += kWave) a.heavy_list[a.n_strands - 1 - (base + i)] = heavy_buf[i];
+        wave_mem_sync();
+        n_heavy = 0;
+    };
+    for (uint32_t base64 = wave * kWave; base64 < a.n_strands; base64 += n_waves * kWave) {
+        const uint32_t rs = base64 + lane;
+        const bool valid = rs < a.n_strands;
+        const uint32_t o = valid ? a.strand_off[rs] : 0;
+        const uint32_t nh = valid ? a.strand_off[rs + 1] - o : 0;
+        if (valid && nh == 0) a.strand_ncand[rs] = 0;
+        bool to_mid = nh > (uint32_t)kLaneHits && nh <= (uint32_t)kWave;
+        const bool heavy = nh > (uint32_t)kWave;
+        uint32_t gnc = 0;
+        uint32_t cs[kLaneCands], ce[kLaneCands], cb[kLaneCands], cn[kLaneCands], ct[kLaneCands];
+#pragma unroll
+        for (int k = 0; k < kLaneCands; k++) cs[k] = ce[k] = cb[k] = cn[k] = ct[k] = 0;
+        bool hopeless = false;
+        if (nh >= 1 && nh <= (uint32_t)kLaneHits) {
+            const uint32_t ns_raw = a.strand_nseeds[rs];
+            hopeless = (ns_raw & kHopeless) != 0;  // k_thin's flag (see kHopeless)
+            const StrandGeom gg = strand_geom(a.read_off, r0 + (rs >> 1), ns_raw);
+            uint64_t key[kLaneHits];
+#pragma unroll
+            for (int i = 0; i < kLaneHits; i++)
+                key[i] = (uint32_t)i < nh ? ((uint64_t)a.hit_ref[o + i] << 32) | a.hit_q[o + i] : ~0ull;
+            // seed_hits.sort(): (reference_offset, query_offset), index.rs:443
+#define MTSV_CX(I, J)                      \
+    {                                      \
+        const uint64_t lo_ = key[I] < key[J] ? key[I] : key[J], hi_ = key[I] < key[J] ? key[J] : key[I]; \
+        key[I] = lo_;                      \
+        key[J] = hi_;                      \
     }
+            MTSV_SORT12(MTSV_CX)
+#undef MTSV_CX
+            // the walk of index.rs:445-485
+            bool have = false;
+            uint32_t w_s = 0, w_e = 0, w_b = 0, w_n = 0, w_t = 0;
+            uint32_t cur_b = 0xffffffffu;
+            DevBin cur{0, 0, 0, 0};
+            auto flush = [&]() {  // index.rs:467-469: the running candidate is kept if it has enough seeds
+                if (have && w_n >= gg.min_seeds) {
+#pragma unroll
+                    for (int k = 0; k < kLaneCands; k++)
+                        if (gnc == (uint32_t)k) {
+                            cs[k] = w_s;
+                            ce[k] = w_e;
+                            cb[k] = w_b;
+                            cn[k] = w_n;
+                            ct[k] = w_t;
+                        }
+                    gnc++;
+                }
+            };
+#pragma unroll
+            for (int i = 0; i < kLaneHits; i++) {
+                if ((uint32_t)i < nh) {
+                    const uint32_t site = (uint32_t)(key[i] >> 32), q = (uint32_t)key[i];
+                    // first bin whose end > site (index.rs:455-458): the sites ascend, so it only changes when they pass its end
+                    if (cur_b == 0xffffffffu || site >= cur.end) {
+                        cur_b = min(find_bin(ix, site), ix.n_bins - 1);
+                        cur = ix.bins[cur_b];
+                    }
+                    uint32_t ws, we;
+                    const bool ok = candidate_window(site, q, cur, gg.L, gg.ED, &ws, &we);
+                    const bool merge = have && ok && cur_b == w_b && ((w_s <= ws && ws < w_e) || (w_s < we && we <= w_e));
+                    if (merge) {  // add_seed_hit, index.rs:216-229
+                        w_s = min(w_s, ws);
+                        w_e = max(w_e, we);
+                        w_n++;
+                    } else {
+                        flush();
+                        have = ok;  // ReferenceCandidate::new, index.rs:472,475
+                        w_s = ws;
+                        w_e = we;
+                        w_b = cur_b;
+                        w_n = 1;
+                        w_t = cur.tax_id;
+                    }
+                }
+            }
+            flush();  // index.rs:481-485
+            if (gnc > (uint32_t)kLaneCands) {  // more candidates than the registers hold: k_coalesce_mid does this strand
+                to_mid = true;
+                gnc = 0;
+            }
+        }
+        {   // the longer strands: 13..64 hits (and the rare overflow above) for k_coalesce_mid, > 64 for k_coalesce_heavy
+            const unsigned long long bm = __ballot(to_mid), bh = __ballot(heavy);
+            if (bm) {
+                if (to_mid) mid_buf[n_mid + __popcll(bm & ((1ull << lane) - 1))] = rs;
+                n_mid += (uint32_t)__popcll(bm);
+                if (n_mid > kMidFlush) flush_mid();
+            }
+            if (bh) {
+                if (heavy) heavy_buf[n_heavy + __popcll(bh & ((1ull << lane) - 1))] = rs;
+                n_heavy += (uint32_t)__popcll(bh);
+                if (n_heavy > kHeavyFlush) flush_heavy();
+            }
+        }
+        const bool mine = nh >= 1 && nh <= (uint32_t)kLaneHits && !to_mid;  // this lane finishes its strand here
+        // stable sort by num_seeds descending (index.rs:369) as a rank; the same-TaxId chain in rank order: a candidate is
+        // verified only after every earlier candidate of its TaxId has failed (index.rs:393), so only the first of each
+        // TaxId starts as work
+        uint32_t rank[kLaneCands], nxt[kLaneCands];
+        bool first[kLaneCands];
+#pragma unroll
+        for (int k = 0; k < kLaneCands; k++) {
+            rank[k] = 0;
+#pragma unroll
+            for (int j = 0; j < kLaneCands; j++)
+                if (j != k && (uint32_t)j < gnc) rank[k] += (cn[j] > cn[k]) || (cn[j] == cn[k] && j < k);
+        }
+#pragma unroll
+        for (int k = 0; k < kLaneCands; k++) {
+            nxt[k] = 0xffffffffu;
+            first[k] = (uint32_t)k < gnc;
+#pragma unroll
+            for (int j = 0; j < kLaneCands; j++)
+                if (j != k && (uint32_t)j < gnc && ct[j] == ct[k]) {
+                    if (rank[j] > rank[k] && rank[j] < nxt[k]) nxt[k] = rank[j];
+                    if (rank[j] < rank[k]) first[k] = false;
+                }
+        }
+        uint32_t n_emit = 0;
+        if (mine) {
+            cand_sum += gnc;
+            if (hopeless) {
+                // the reference prefilters each candidate of such a strand (up to max_candidates) and none can pass: that
+                // work is accounted here and the strand leaves the pipeline (no candidates to resolve)
+                a.strand_ncand[rs] = 0;
+                ver_sum += min(gnc, maxc);
+#pragma unroll
+                for (int k = 0; k < kLaneCands; k++)
+                    if ((uint32_t)k < gnc && rank[k] < maxc) win_sum += ce[k] - cs[k];
+            } else {
+                a.strand_ncand[rs] = gnc;
+#pragma unroll
+                for (int k = 0; k < kLaneCands; k++)
+                    if ((uint32_t)k < gnc) {
+                        a.cand[o + rank[k]] = make_uint4(cs[k], ce[k], cb[k], rs);
+                        a.cand_next[o + rank[k]] = nxt[k];
+                        a.cand_status[o + rank[k]] = 0;
+                        n_emit += first[k] && rank[k] < maxc;
+                    }
+            }
+        }
+        {   // the strands' first candidates of every TaxId become work items: lane-major into the wavefront's buffer
+            uint32_t incl = n_emit;
+#pragma unroll
+            for (int d = 1; d < kWave; d <<= 1) {
+                const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+                if (lane >= (uint32_t)d) incl += up;
+            }
+            const uint32_t total = (uint32_t)__shfl((int)incl, kWave - 1);
+            uint32_t at = pend + incl - n_emit;
+            if (n_emit) {
+#pragma unroll
+                for (int k = 0; k < kLaneCands; k++)
+                    if ((uint32_t)k < gnc && first[k] && rank[k] < maxc) pend_buf[at++] = o + rank[k];
+            }
+            pend += total;
+            if (pend > kPendFlush) flush_pend();
+        }
+    }
+    if (pend) flush_pend();
+    if (n_mid) flush_mid();
+    if (n_heavy) flush_heavy();
     for (int d = 32; d > 0; d >>= 1) {
         cand_sum += __shfl_down(cand_sum, d);
         ver_sum += __shfl_down(ver_sum, d);
@@ -520,7 +581,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
     }
 }
 
-// Strands of the list with 17..64 seed hits: one wavefront each, everything in registers.
+// Strands of the list with up to 64 seed hits (those k_coalesce passes on): one wavefront each, everything in registers.
 // one strand of 17..64 seed hits on one wavefront; returns its candidate count.  Not inlined on purpose: the
 // caller's loop state and the argument block would otherwise all be live across this body (SGPR spills).
 __device__ __attribute__((noinline)) uint32_t coalesce_mid_strand(const DevIndexView& ix, const CoalesceArgs& a, uint32_t rs, uint32_t o,
