@@ -1079,7 +1079,7 @@ __device__ inline int row_suffix_incl16(int v) {
     return v;
 }
 
-constexpr uint32_t kDiagBuf = 128;  // decisions a wavefront of k_sw_diag buffers per list
+constexpr uint32_t kDiagBuf = 512;  // decisions a wavefront of k_sw_diag buffers per list (128: one returning atomic per ~120 entries = 147 k per 10 M reads on each counter, ~11 ns each)
 
 // NW: words of four read positions per lane (16 * 4 * NW >= the longest read of the pass)
 #ifndef MTSV_DIAG_OCC
