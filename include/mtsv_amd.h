@@ -209,6 +209,13 @@ int mtsv_batch_run(mtsv_batch *b, const mtsv_params *params); /* synchronous: re
  * fields index the whole host batch.  Stats cover all slices. */
 int mtsv_batch_run_host(mtsv_batch *b, const uint8_t *bases, const uint64_t *read_off,
                         uint64_t n_reads, const mtsv_params *params);
+/* The same for a batch that lies in n_parts pieces (a host that parses its input in blocks hands several blocks to one
+ * call -- larger passes on the device -- without putting them together first): part k holds n_reads[k] reads, bases[k]
+ * with read_off[k][0 .. n_reads[k]]; the reads are numbered through the parts in order, and mtsv_batch_download returns
+ * one hit list over all of them.  (The reference has no such call: its worker closure takes one read,
+ * src/binner.rs:77-131.) */
+int mtsv_batch_run_host_parts(mtsv_batch *b, int n_parts, const uint8_t *const *bases, const uint64_t *const *read_off,
+                              const uint64_t *n_reads, const mtsv_params *params);
 int mtsv_batch_stats_get(const mtsv_batch *b, mtsv_batch_stats *st);
 int mtsv_batch_download(mtsv_batch *b, mtsv_hit **hits, uint64_t *n_hits);
 void mtsv_batch_free(mtsv_batch *b);

@@ -61,7 +61,7 @@ EXPORTS = [
     "mtsv_last_error", "mtsv_version", "mtsv_params_default", "mtsv_device_count",
     "mtsv_index_load", "mtsv_index_build", "mtsv_index_build_fasta", "mtsv_index_write",
     "mtsv_index_info", "mtsv_index_free", "mtsv_set_build_device", "mtsv_index_to_device", "mtsv_bin_batch",
-    "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run", "mtsv_batch_run_host",
+    "mtsv_hits_free", "mtsv_batch_create", "mtsv_batch_upload", "mtsv_batch_run", "mtsv_batch_run_host", "mtsv_batch_run_host_parts",
     "mtsv_batch_stats_get", "mtsv_batch_set_verify_mode", "mtsv_batch_download", "mtsv_batch_free", "mtsv_format_results",
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads", "mtsv_bin_batch_workspace_reads",
     "mtsv_bin_batch_multi", "mtsv_bin_batch_chunks", "mtsv_set_default_verify_mode",
@@ -104,6 +104,7 @@ def lib():
         L.mtsv_batch_upload.argtypes = [vp, vp, vp, u64]
         L.mtsv_batch_run.argtypes = [vp, C.POINTER(Params)]
         L.mtsv_batch_run_host.argtypes = [vp, vp, vp, u64, C.POINTER(Params)]
+        L.mtsv_batch_run_host_parts.argtypes = [vp, i32, vp, vp, vp, C.POINTER(Params)]
         L.mtsv_batch_set_verify_mode.argtypes = [vp, i32]
         L.mtsv_batch_stats_get.argtypes = [vp, C.POINTER(BatchStats)]
         L.mtsv_batch_download.argtypes = [vp, C.POINTER(vp), C.POINTER(u64)]
@@ -321,6 +322,16 @@ class Batch:
         read_off = np.ascontiguousarray(read_off, dtype=np.uint64)
         _check(lib().mtsv_batch_run_host(self.h, bases.ctypes.data, read_off.ctypes.data, len(read_off) - 1,
                                          C.byref(params)))
+
+    def run_host_parts(self, parts, params=None):
+        """parts: [(bases u8 array, read_off u64 array), ...]; the reads are numbered through the parts in order"""
+        params = params or default_params()
+        keep = [(np.ascontiguousarray(b, dtype=np.uint8), np.ascontiguousarray(o, dtype=np.uint64)) for b, o in parts]
+        k = len(keep)
+        bp = (C.c_void_p * k)(*[b.ctypes.data for b, _ in keep])
+        op = (C.c_void_p * k)(*[o.ctypes.data for _, o in keep])
+        nr = (C.c_uint64 * k)(*[len(o) - 1 for _, o in keep])
+        _check(lib().mtsv_batch_run_host_parts(self.h, k, bp, op, nr, C.byref(params)))
 
     def stats(self):
         s = BatchStats()

@@ -812,6 +812,14 @@ bool pinned_hits_release(void* p) { return p && pool().put(p); }
 //   * a finished range's hits leave for the pinned result array at once, in read order, on a third stream.
 // ---------------------------------------------------------------------------------------------
 void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p, uint64_t read_base) {
+    const HostPart one{bases, read_off, n};
+    run_host_parts(&one, 1, p, read_base);
+}
+
+// The same for a batch that lies in several pieces (mtsv_batch_run_host_parts: a host that parses its input in blocks hands
+// several blocks to one call -- larger passes on the device -- without putting them together first).  The reads are
+// numbered through the parts in order.
+void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params& p, uint64_t read_base) {
     const double t_entry = now_s();
     HIP_CHECK(hipSetDevice(di->device));
     std::vector<Batch*> ls{this};
@@ -827,11 +835,43 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
         HIP_CHECK(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_high));
         HIP_CHECK(hipStreamCreateWithPriority(&copy_stream2, hipStreamNonBlocking, prio_high));
     }
-    if (n && read_off[n] < read_off[0]) throw std::runtime_error("arg: read_off is not ascending");
-    const uint64_t first_base = n ? read_off[0] : 0, total_bases = n ? read_off[n] - first_base : 0;
-    // bases in page-locked memory (mtsv_host_alloc / mtsv_host_register) go to the GPU from where they lie
-    const bool direct = n && total_bases && host_pinned(bases + first_base, total_bases) && !getenv("MTSV_STAGE_ALWAYS");
-    if (trace) fprintf(stderr, "[run_host] input %s\n", direct ? "page-locked: copied from the caller's buffer" : "pageable: staged");
+    // the parts as one batch: reads numbered through them, a virtual byte offset that ascends through them
+    struct PartView {
+        const uint8_t* bases;
+        const uint64_t* off;
+        uint64_t n, first, virt;
+        bool pinned;
+    };
+    std::vector<PartView> pv;
+    uint64_t n = 0, total_bases = 0;
+    for (int k = 0; k < n_parts; k++) {
+        const HostPart& hp = parts[k];
+        if (!hp.n) continue;
+        if (!hp.read_off || hp.read_off[hp.n] < hp.read_off[0]) throw std::runtime_error("arg: read_off is not ascending");
+        const uint64_t nb = hp.read_off[hp.n] - hp.read_off[0];
+        if (nb && !hp.bases) throw std::runtime_error("arg: null bases");
+        // bases in page-locked memory (mtsv_host_alloc / mtsv_host_register) go to the GPU from where they lie
+        const bool pin = nb && host_pinned(hp.bases + hp.read_off[0], nb) && !getenv("MTSV_STAGE_ALWAYS");
+        pv.push_back(PartView{hp.bases, hp.read_off, hp.n, n, total_bases, pin});
+        n += hp.n;
+        total_bases += nb;
+    }
+    const uint64_t first_base = 0;
+    auto part_of = [&](uint64_t r) {  // the part read r lies in (r == n: the last part)
+        size_t k = pv.size() - 1;
+        while (k > 0 && pv[k].first > r) k--;
+        return k;
+    };
+    auto RO = [&](uint64_t r) {  // virtual offset of read r's first base (r == n: the end of the batch)
+        if (pv.empty()) return (uint64_t)0;
+        const PartView& v = pv[part_of(r)];
+        return v.virt + (v.off[r - v.first] - v.off[0]);
+    };
+    bool any_staged = false, any_direct = false;
+    for (auto& v : pv) (v.pinned ? any_direct : any_staged) = true;
+    const bool direct = !any_staged;
+    if (trace) fprintf(stderr, "[run_host] input %s%s\n", direct ? "page-locked: copied from the caller's buffer" : "pageable: staged",
+                       any_staged && any_direct ? " (some parts page-locked)" : "");
 
     // ---- arenas: segments of at most kArenaBases bases / kArenaReads reads (u32 offsets inside a segment) ----
     uint64_t arena_bases = kArenaBases, arena_reads = kArenaReads;
@@ -976,11 +1016,12 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                 {
                     // largest e with read_off[e] - read_off[r] <= chunk_bytes (at least one read)
                     uint64_t lo = r + 1, hi = n;
-                    const uint64_t lim = read_off[r] + chunk_bytes;
-                    if (read_off[hi] > lim) {
+                    hi = pv[part_of(r)].first + pv[part_of(r)].n;  // a chunk is copied from one part
+                    const uint64_t lim = RO(r) + chunk_bytes;
+                    if (RO(hi) > lim) {
                         while (lo < hi) {
                             const uint64_t mid = (lo + hi + 1) / 2;
-                            if (read_off[mid] <= lim) lo = mid;
+                            if (RO(mid) <= lim) lo = mid;
                             else hi = mid - 1;
                         }
                         hi = lo;
@@ -988,18 +1029,18 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     e = hi;
                 }
                 Arena* ar = &arena[seg & 1];
-                if (read_off[e] - seg_first_base > ar->cap_bases || e - seg_first_read > ar->cap_reads) {
+                if (RO(e) - seg_first_base > ar->cap_bases || e - seg_first_read > ar->cap_reads) {
                     // does not fit the segment any more: shorten to what fits, or open the next segment
                     uint64_t lo = r, hi = e;
                     while (lo < hi) {
                         const uint64_t mid = (lo + hi + 1) / 2;
-                        if (read_off[mid] - seg_first_base <= ar->cap_bases && mid - seg_first_read <= ar->cap_reads) lo = mid;
+                        if (RO(mid) - seg_first_base <= ar->cap_bases && mid - seg_first_read <= ar->cap_reads) lo = mid;
                         else hi = mid - 1;
                     }
                     if (lo == r) {
                         if (r == seg_first_read) throw std::runtime_error("limit: one read holds more bases than an input segment (" + std::to_string(ar->cap_bases) + ")");
                         seg++;
-                        seg_first_base = read_off[r];
+                        seg_first_base = RO(r);
                         seg_first_read = r;
                         ar = &arena[seg & 1];
                         {
@@ -1016,7 +1057,9 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                     }
                     e = lo;
                 }
-                const uint64_t cnt = e - r, b0 = read_off[r], nb = read_off[e] - b0;
+                const PartView& src_part = pv[part_of(r)];
+                const uint64_t* poff = src_part.off + (r - src_part.first);  // this chunk's offsets inside its part
+                const uint64_t cnt = e - r, b0 = RO(r), nb = RO(e) - b0;
                 const uint64_t dst_b = b0 - seg_first_base, dst_r = r - seg_first_read;
                 // offsets relative to the segment's first base; h_off_all[seg ... ] holds them at index (read + seg) so that
                 // every segment has its own closing entry
@@ -1025,16 +1068,16 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
                 uint32_t ml = 0;
                 if (r == seg_first_read) ho[0] = 0;  // (else the previous chunk wrote this entry; a lane may be reading it)
                 for (uint64_t i = 1; i <= cnt; i++) {
-                    if (read_off[r + i] < read_off[r + i - 1]) throw std::runtime_error("arg: read_off is not ascending");
-                    const uint32_t v = (uint32_t)(read_off[r + i] - seg_first_base);
+                    if (poff[i] < poff[i - 1]) throw std::runtime_error("arg: read_off is not ascending");
+                    const uint32_t v = (uint32_t)(b0 + (poff[i] - poff[0]) - seg_first_base);
                     ml = std::max(ml, v - ho[i - 1]);
                     ho[i] = v;
                 }
                 const double t0 = now_s();
                 hipEvent_t ev = event_for(k);
                 if (nb) {
-                    const uint8_t* src = bases + b0;
-                    if (!direct) {
+                    const uint8_t* src = src_part.bases + poff[0];
+                    if (!src_part.pinned) {
                         uint8_t* hs = h_stage[k % kStage];
                         if (k >= kStage) {  // its last copy must have left (polled, like the watcher)
                             for (;;) {

@@ -98,6 +98,12 @@ struct Batch {
     void run(const mtsv_params& p);
     // read_base: added to the `read` field of every hit (a caller that shards one host batch over devices)
     void run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n, const mtsv_params& p, uint64_t read_base = 0);
+    struct HostPart {
+        const uint8_t* bases;
+        const uint64_t* read_off;  // n + 1 offsets into bases
+        uint64_t n;
+    };
+    void run_host_parts(const HostPart* parts, int n_parts, const mtsv_params& p, uint64_t read_base = 0);
     void download(mtsv_hit** hits, uint64_t* n);
     // the hits of the last run, still in HBM (keep_on_device was set), into caller memory that holds n == total_hits entries
     void download_into(mtsv_hit* dst, uint64_t n);

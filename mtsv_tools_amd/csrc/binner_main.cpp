@@ -230,7 +230,7 @@ struct Args {
                 max_hits = "2000", tune_max_hits = "200", max_assign, max_cand, read_offset = "0";
     bool verbose = false, force = false, parse_only = false;
     std::vector<int> devices{0};
-    uint64_t batch_reads = 1u << 18;  // measured end to end on 32 M reads: 256 Ki 41 M reads/s, 512 Ki 38, 1 Mi 31 (pipeline granularity)
+    uint64_t batch_reads = 1u << 17;  // parser blocks of ~40 MB; the GPU workers take up to 1 Mi reads of them per library call. End to end on 32 M reads: 64 Ki .., 128 Ki 70 M reads/s, 256 Ki 54, 512 Ki 37
 };
 
 [[noreturn]] void usage_error(const std::string& m) {
@@ -631,7 +631,8 @@ int main(int argc, char** argv) {
     // the workers' workspaces (one index): part of the device set-up, like making the index resident
     std::vector<mtsv_batch*> ws_ready(chunked ? 0 : a.devices.size(), nullptr);
     for (size_t wk = 0; wk < ws_ready.size(); wk++)
-        if (mtsv_batch_create(idx[0], a.devices[wk], mtsv_bin_batch_workspace_reads(a.batch_reads), 1 << 22, 0, &ws_ready[wk]) != MTSV_OK) {
+        if (mtsv_batch_create(idx[0], a.devices[wk], mtsv_bin_batch_workspace_reads(std::max<uint64_t>(a.batch_reads, 1ull << 20) + a.batch_reads), 1 << 22, 0,
+                              &ws_ready[wk]) != MTSV_OK) {
             logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
             return 2;
         }
@@ -643,7 +644,8 @@ int main(int argc, char** argv) {
         // stock: the parser's window of blocks plus what sits in the queues and with the workers
         if (const char* e = getenv("MTSV_INGEST_BLOCK")) plain_block_bytes = strtoull(e, nullptr, 10);
         const uint64_t est = plain_block_bytes ? plain_block_bytes : (uint64_t)a.batch_reads * 320;
-        pool.stock(std::min<size_t>(2 * host_threads + 2 + 3 * (a.devices.size() + 1), 64), std::min<uint64_t>(est / 2 + (1 << 20), 512ull << 20));
+        const uint64_t per_call = std::min<uint64_t>(8, std::max<uint64_t>(1, std::max<uint64_t>(a.batch_reads, 1ull << 20) / std::max<uint64_t>(a.batch_reads, 1)));
+        pool.stock(std::min<size_t>(2 * host_threads + 2 + (size_t)(2 * per_call + 1) * (a.devices.size() + 1), 96), std::min<uint64_t>(est / 2 + (1 << 20), 512ull << 20));
     }
     logmsg("INFO", "Beginning queries.");
     struct timespec w0;
@@ -665,8 +667,9 @@ int main(int argc, char** argv) {
     struct Work {
         std::unique_ptr<ReadBlock> rb;
         uint64_t seq = 0;
-        mtsv_hit* hits = nullptr;
+        mtsv_hit* hits = nullptr;  // this batch's hits: a slice of the array hits_owner holds (read numbers relative to the batch)
         uint64_t n_hits = 0;
+        std::shared_ptr<void> hits_owner;  // the result array of the library call the batch was part of
     };
     struct Queue {
         std::mutex mu;
@@ -679,6 +682,14 @@ int main(int argc, char** argv) {
             cv.wait(lk, [&] { return q.size() < cap || closed; });
             q.push_back(std::move(w));
             cv.notify_all();
+        }
+        std::unique_ptr<Work> try_pop() {  // nullptr when nothing is waiting
+            std::lock_guard<std::mutex> lk(mu);
+            if (q.empty()) return nullptr;
+            auto w = std::move(q.front());
+            q.pop_front();
+            cv.notify_all();
+            return w;
         }
         std::unique_ptr<Work> pop() {
             std::unique_lock<std::mutex> lk(mu);
@@ -697,8 +708,14 @@ int main(int argc, char** argv) {
     };
     const size_t n_workers = chunked ? 2 : a.devices.size();
     Queue parsed, done;
-    parsed.cap = n_workers + 1;
-    done.cap = n_workers + 1;
+    // One library call takes every batch that is waiting, up to kGroupReads reads (mtsv_batch_run_host_parts): the device
+    // is several times faster on passes of a million reads than on a quarter of that (a pass costs ~2.5 ms before it does
+    // any work), while the parser is fastest on blocks of ~80 MB.
+    uint64_t kGroupReads = std::max<uint64_t>(a.batch_reads, 1ull << 20);
+    if (const char* e = getenv("MTSV_CLI_GROUP_READS")) kGroupReads = std::max<uint64_t>(a.batch_reads, strtoull(e, nullptr, 10));
+    const size_t group_max = (size_t)std::min<uint64_t>(32, std::max<uint64_t>(1, kGroupReads / std::max<uint64_t>(a.batch_reads, 1)));
+    parsed.cap = n_workers * group_max + 1;
+    done.cap = n_workers * group_max + 1;
     std::mutex err_mu;
     int exit_code = 0;
     auto set_code = [&](int c) {
@@ -840,7 +857,7 @@ int main(int argc, char** argv) {
             } else {
                 fmt(0);
             }
-            mtsv_hits_free(w->hits);
+            w->hits_owner.reset();  // (the array goes back to the library's pool with the last batch of its call)
             acc(t_fmt, now() - t_f0);
             bool ok = true;
             for (unsigned k = 0; k < parts; k++)
@@ -895,20 +912,37 @@ int main(int argc, char** argv) {
         mtsv_batch* ws = chunked ? nullptr : ws_ready[wk];  // one index: this worker's own workspace on its device
         for (;;) {
             const double t_p = now();
-            auto w = parsed.pop();
+            std::vector<std::unique_ptr<Work>> group;
+            group.push_back(parsed.pop());
             acc(t_gpu_wait, now() - t_p);
-            if (!w) break;
+            if (!group[0]) break;
             if (failed()) continue;  // drain
+            uint64_t group_reads = group[0]->rb->n();
+            while (!chunked && group.size() < group_max && group_reads < kGroupReads) {  // whatever else is ready, in order
+                auto more = parsed.try_pop();
+                if (!more) break;
+                group_reads += more->rb->n();
+                group.push_back(std::move(more));
+            }
             const double t_g = now();
             int rc;
+            mtsv_hit* hits = nullptr;
+            uint64_t n_hits = 0;
             if (chunked) {
+                auto& w = group[0];
                 rc = mtsv_bin_batch_chunks(idx.data(), chunk_dev.data(), (int)idx.size(), w->rb->bases.data(), w->rb->off.data(), w->rb->n(), &p,
-                                           &w->hits, &w->n_hits);
+                                           &hits, &n_hits);
             } else {
-                const uint64_t nr = w->rb->n();
-                rc = MTSV_OK;
-                if (rc == MTSV_OK) rc = mtsv_batch_run_host(ws, w->rb->bases.data(), w->rb->off.data(), nr, &p);
-                if (rc == MTSV_OK) rc = mtsv_batch_download(ws, &w->hits, &w->n_hits);
+                std::vector<const uint8_t*> pb;
+                std::vector<const uint64_t*> po;
+                std::vector<uint64_t> pn;
+                for (auto& w : group) {
+                    pb.push_back(w->rb->bases.data());
+                    po.push_back(w->rb->off.data());
+                    pn.push_back(w->rb->n());
+                }
+                rc = mtsv_batch_run_host_parts(ws, (int)group.size(), pb.data(), po.data(), pn.data(), &p);
+                if (rc == MTSV_OK) rc = mtsv_batch_download(ws, &hits, &n_hits);
             }
             if (rc != MTSV_OK) {
                 logmsg("ERROR", std::string("Error running query: ") + mtsv_last_error());
@@ -916,7 +950,22 @@ int main(int argc, char** argv) {
                 continue;
             }
             acc(t_gpu, now() - t_g);
-            done.push(std::move(w));
+            // every batch gets its slice of the hits, read numbers relative to the batch
+            std::shared_ptr<void> owner(hits, [](void* q) { mtsv_hits_free((mtsv_hit*)q); });
+            uint64_t first = 0, at = 0;
+            for (auto& w : group) {
+                const uint64_t nr = w->rb->n();
+                uint64_t end = at;
+                while (end < n_hits && hits[end].read < first + nr) end++;
+                if (first)
+                    for (uint64_t i = at; i < end; i++) hits[i].read -= first;
+                w->hits = hits + at;
+                w->n_hits = end - at;
+                w->hits_owner = owner;
+                at = end;
+                first += nr;
+            }
+            for (auto& w : group) done.push(std::move(w));
         }
         if (ws) mtsv_batch_free(ws);
     };

@@ -251,6 +251,19 @@ int mtsv_batch_run_host(mtsv_batch* b, const uint8_t* bases, const uint64_t* rea
     GUARD(b->impl.run_host(bases, read_off, n_reads, *params))
 }
 
+int mtsv_batch_run_host_parts(mtsv_batch* b, int n_parts, const uint8_t* const* bases, const uint64_t* const* read_off,
+                              const uint64_t* n_reads, const mtsv_params* params) {
+    if (!b || n_parts < 0 || (n_parts && (!bases || !read_off || !n_reads)) || !params) return fail_arg("null argument");
+    GUARD({
+        std::vector<mtsv::Batch::HostPart> parts((size_t)n_parts);
+        for (int k = 0; k < n_parts; k++) {
+            if (n_reads[k] && !read_off[k]) throw std::runtime_error("arg: null read_off");
+            parts[(size_t)k] = mtsv::Batch::HostPart{bases[k], read_off[k], n_reads[k]};
+        }
+        b->impl.run_host_parts(parts.data(), n_parts, *params);
+    })
+}
+
 int mtsv_batch_stats_get(const mtsv_batch* b, mtsv_batch_stats* st) {
     if (!b || !st) return fail_arg("null argument");
     *st = b->impl.stats;

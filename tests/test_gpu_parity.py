@@ -842,3 +842,37 @@ def test_edit_distance_bound_of_the_prefilter_in_all_three_outcomes(tmp_path, mo
         else:
             assert st["n_sw_bound_refuted"] == 0 and st["sw_cell_pairs"] > ref
         b.close()
+
+
+def test_run_host_parts_equals_one_batch(tricky, medium):
+    """mtsv_batch_run_host_parts: the same reads handed over in several pieces (uneven, an empty one among them, one in
+    page-locked memory) give the hits of the one-piece call, read numbers running through the parts"""
+    ix, orc, reads = tricky
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want, _ = orc.bin_batch(bases, off, both_params()[1], threads=8)
+    cuts = [0, 7, 7, 60, len(reads) // 2, len(reads)]
+    parts = []
+    for a, b in zip(cuts, cuts[1:]):
+        pb, po = helpers.reads_to_batch(reads[a:b])
+        parts.append((pb, po))
+    b = M.Batch(ix, 0, 64, 1 << 16)            # a workspace far smaller than the batch
+    b.run_host_parts(parts)
+    assert_same_hits(b.download(), want)
+    b.run_host_parts([])                       # no parts at all
+    assert len(b.download()) == 0
+    b.close()
+    mix, mbases, moff = medium                 # 150-base reads: parts cut anywhere, one of them page-locked
+    mix.to_device(0)
+    n = len(moff) - 1
+    whole = mix.bin_batch(mbases, moff, device=0)
+    c1, c2 = n // 3 + 11, 2 * n // 3 + 5
+    hb = M.HostBuffer(int(moff[c2] - moff[c1]))
+    hb.array[:] = mbases[int(moff[c1]):int(moff[c2])]
+    parts = [(mbases[: int(moff[c1])], moff[: c1 + 1]), (hb.array, moff[c1: c2 + 1] - moff[c1]),
+             (mbases[int(moff[c2]):], moff[c2:] - moff[c2])]
+    b = M.Batch(mix, 0, 300_000, 300_000 * 150)
+    b.run_host_parts(parts)
+    assert_same_hits(b.download(), whole)
+    b.close()
+    hb.close()
