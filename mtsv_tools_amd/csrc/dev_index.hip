@@ -207,7 +207,7 @@ std::unique_ptr<DeviceIndex> upload_index(const HostIndex& hx, int device, uint3
     if (sentinel_row == UINT64_MAX) throw std::runtime_error("format: bwt holds no sentinel");
 
     // ---- text codes, SA samples, bins ---------------------------------------------------------
-    std::vector<uint8_t> codes(((uint64_t)n + 3) / 4 * 4 + 16, (uint8_t)7);  // dword-padded for load16()
+    std::vector<uint8_t> codes(((uint64_t)n + 15) / 16 * 16 + 32, (uint8_t)7);  // padded for load16(): two aligned 16-byte loads from any position
     parallel_ranges(n, threads, [&](uint64_t lo, uint64_t hi, int) {
         for (uint64_t i = lo; i < hi; i++) codes[i] = (uint8_t)sym_code(hx.text[i]);
     });

@@ -42,20 +42,25 @@ __device__ inline int row_shr1(int v) { return __builtin_amdgcn_update_dpp(0, v,
 
 __device__ inline uint32_t group_ballot(bool p, uint32_t group) { return (uint32_t)(__ballot(p) >> (group * kGroup)) & 0xffffu; }
 
-// 16 window symbols starting at text[pos] (any alignment) as four little-endian dwords; bytes past
-// the text read as 7.  Aligned dword loads + v_alignbyte.
+// 16 window symbols starting at text[pos] (any alignment) as four little-endian dwords; bytes past the text read as 7
+// (the text allocation is padded with 7 to a 16-byte multiple plus 32: dev_index.hip).  Two aligned 16-byte loads and a
+// select instead of five dword loads: a lane's window lies anywhere in a multi-GB text, so every load instruction of a
+// wavefront touches 64 different lines, and it is the number of such instructions that the texture path pays for.
 __device__ inline uint4 load16(const uint8_t* __restrict__ text, uint32_t n, uint32_t pos) {
-    const uint32_t* t32 = reinterpret_cast<const uint32_t*>(text);
-    const uint32_t w0 = pos >> 2, sh = pos & 3;
-    const uint32_t lastw = (n - 1) >> 2;  // text allocations are padded to a dword multiple
-    uint32_t d[5];
-#pragma unroll
-    for (int k = 0; k < 5; k++) d[k] = (w0 + k <= lastw) ? t32[w0 + k] : 0x07070707u;
+    (void)n;
+    const uint4* t128 = reinterpret_cast<const uint4*>(text);
+    const uint32_t w = pos >> 4, dsel = (pos >> 2) & 3u, sh = pos & 3u;
+    const uint4 a = t128[w], b = t128[w + 1];
+    const uint32_t e0 = dsel == 0 ? a.x : dsel == 1 ? a.y : dsel == 2 ? a.z : a.w;
+    const uint32_t e1 = dsel == 0 ? a.y : dsel == 1 ? a.z : dsel == 2 ? a.w : b.x;
+    const uint32_t e2 = dsel == 0 ? a.z : dsel == 1 ? a.w : dsel == 2 ? b.x : b.y;
+    const uint32_t e3 = dsel == 0 ? a.w : dsel == 1 ? b.x : dsel == 2 ? b.y : b.z;
+    const uint32_t e4 = dsel == 0 ? b.x : dsel == 1 ? b.y : dsel == 2 ? b.z : b.w;
     uint4 r;
-    r.x = __builtin_amdgcn_alignbyte(d[1], d[0], sh);
-    r.y = __builtin_amdgcn_alignbyte(d[2], d[1], sh);
-    r.z = __builtin_amdgcn_alignbyte(d[3], d[2], sh);
-    r.w = __builtin_amdgcn_alignbyte(d[4], d[3], sh);
+    r.x = __builtin_amdgcn_alignbyte(e1, e0, sh);
+    r.y = __builtin_amdgcn_alignbyte(e2, e1, sh);
+    r.z = __builtin_amdgcn_alignbyte(e3, e2, sh);
+    r.w = __builtin_amdgcn_alignbyte(e4, e3, sh);
     return r;
 }
 
@@ -1398,11 +1403,18 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     uint32_t mA = 0, mC = 0, mG = 0, mT = 0, wild = 0;
                     if (q0 + 31 >= 0) {
                         const long long byte0 = (long long)b0 + q0;  // may point before this read (or the buffer)
-                        const long long w0 = byte0 >> 2;
-                        const uint32_t sh = (uint32_t)(byte0 & 3);
+                        const uint32_t sh = (uint32_t)(byte0 & 3), dsel = (uint32_t)(byte0 >> 2) & 3u;
+                        // the word's 33..36 bytes as three aligned 16-byte loads and a select (see load16): nine dword loads
+                        // per word made the set-up two thirds of the kernel's load instructions
+                        const long long q16 = byte0 >> 4;
+                        const uint4* bases128 = reinterpret_cast<const uint4*>(bases32);
+                        const uint4 zero4 = make_uint4(0, 0, 0, 0);
+                        const uint4 l0 = q16 >= 0 ? bases128[q16] : zero4, l1 = q16 + 1 >= 0 ? bases128[q16 + 1] : zero4,
+                                    l2 = q16 + 2 >= 0 ? bases128[q16 + 2] : zero4;
+                        const uint32_t dd[12] = {l0.x, l0.y, l0.z, l0.w, l1.x, l1.y, l1.z, l1.w, l2.x, l2.y, l2.z, l2.w};
                         uint32_t d[9];
 #pragma unroll
-                        for (int j = 0; j < 9; j++) d[j] = (w0 + j >= 0 && q0 + 4 * j + 3 >= 0) ? bases32[w0 + j] : 0u;
+                        for (int j = 0; j < 9; j++) d[j] = dsel == 0 ? dd[j] : dsel == 1 ? dd[j + 1] : dsel == 2 ? dd[j + 2] : dd[j + 3];
 #pragma unroll
                         for (int j = 0; j < 8; j++) {
                             const uint32_t four = __builtin_amdgcn_alignbyte(d[j + 1], d[j], sh);
@@ -1465,13 +1477,9 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             }
             const uint32_t Wn = c.y - c.x;
             int score = (int)L, best = (int)L;  // D[L][0] = L
-            // The window's columns arrive 16 at a time, three fetches ahead of the recurrence: a lane's window is at a
-            // random place of a multi-GB text (a TLB miss and an HBM miss per fetch), and a wavefront that is alone on its
-            // SIMD -- every short work list -- has nothing else to cover them with.
-            const uint4 none = make_uint4(0, 0, 0, 0);
-            uint4 q0 = Wn ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 0) : none;
-            uint4 q1 = Wn > 16 ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 16) : none;
-            uint4 q2 = Wn > 32 ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 32) : none;
+            // The window's columns arrive 16 at a time, one fetch ahead of the recurrence (three ahead measured the same and
+            // cost eight registers: a wavefront of occupancy here)
+            uint4 nxt4 = Wn ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 0) : make_uint4(0, 0, 0, 0);
             const uint32_t* lane_tab = &eq_tab[0][0][tid];
             uint32_t j0 = 0;
             for (; j0 < Wn; j0 += 16) {
@@ -1479,10 +1487,8 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     if (best <= (int)ED) break;
                     if (best > 2 * (int)ED && score - (int)(Wn - j0) > 2 * (int)ED) break;
                 }
-                const uint4 cur = q0;
-                q0 = q1;
-                q1 = q2;
-                if (j0 + 48 < Wn) q2 = fetch_cols<BOUND>(ix, c.x, c.y, strand, j0 + 48);
+                const uint4 cur = nxt4;
+                if (j0 + 16 < Wn) nxt4 = fetch_cols<BOUND>(ix, c.x, c.y, strand, j0 + 16);  // prefetch the next 16 columns
                 const uint32_t lim = min(16u, Wn - j0);
 #pragma unroll
                 for (int jj = 0; jj < 16; jj++) {
@@ -1490,24 +1496,26 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                         const uint32_t word = jj < 4 ? cur.x : jj < 8 ? cur.y : jj < 12 ? cur.z : cur.w;
                         const uint32_t tc = (word >> ((jj & 3) * 8)) & 0xffu;
                         const uint32_t* row = lane_tab + tc * (W * 256);
-                        uint32_t hp = 0, hm = 0;  // horizontal delta entering word 0 is 0 (first row all zeros)
+                        // One word step in 12 vector instructions: the horizontal deltas enter a word as bit 31 of the word
+                        // below (v_alignbit_b32 shifts them in), and the delta entering word 0 is 0 (first row all zeros).
+                        uint32_t ph_below = 0, mh_below = 0;
 #pragma unroll
                         for (int k = 0; k < W; k++) {
-                            uint32_t Eq = row[k * 256];
+                            const uint32_t Eq = row[k * 256];
                             const uint32_t pv = Pv[k], mv = Mv[k];
                             const uint32_t Xv = Eq | mv;
-                            Eq |= hm;
-                            const uint32_t Xh = (((Eq & pv) + pv) ^ pv) | Eq;
-                            uint32_t Ph = mv | ~(Xh | pv);
-                            uint32_t Mh = pv & Xh;
-                            const uint32_t op = Ph >> 31, om = Mh >> 31;
-                            Ph = (Ph << 1) | hp;
-                            Mh = (Mh << 1) | hm;
-                            Pv[k] = Mh | ~(Xv | Ph);
-                            Mv[k] = Ph & Xv;
-                            hp = op;
-                            hm = om;
+                            const uint32_t Eqh = k ? (Eq | (mh_below >> 31)) : Eq;
+                            const uint32_t Xh = __builtin_amdgcn_bitop3_b32((Eqh & pv) + pv, pv, Eqh, 0xBE);  // (sum ^ pv) | Eqh
+                            const uint32_t Ph = mv | ~(Xh | pv);
+                            const uint32_t Mh = pv & Xh;
+                            const uint32_t Phs = k ? __builtin_amdgcn_alignbit(Ph, ph_below, 31) : (Ph << 1);  // (Ph << 1) | carry
+                            const uint32_t Mhs = k ? __builtin_amdgcn_alignbit(Mh, mh_below, 31) : (Mh << 1);
+                            Pv[k] = Mhs | ~(Xv | Phs);
+                            Mv[k] = Phs & Xv;
+                            ph_below = Ph;
+                            mh_below = Mh;
                         }
+                        const uint32_t hp = ph_below >> 31, hm = mh_below >> 31;
                         score += (int)hp - (int)hm;  // the read's last base is bit 31 of the last word
                         best = min(best, score);
                     }
