@@ -262,7 +262,7 @@ void Batch::finish_lane() {
     stats.edit_ms = edit_ms_acc;
     stats.myers_columns = h_counters[19];
     stats.n_sw_bound_refuted = h_counters[20];
-    stats.n_sw_passed = sw_passed_acc;
+    stats.n_sw_passed = sw_passed_acc + h_counters[21];  // (+ the successors k_edit_myers' list mode passed by its own bound)
     stats.lf_steps = h_counters[2];
     stats.n_candidates = h_counters[3];
     stats.n_verified = h_counters[4];

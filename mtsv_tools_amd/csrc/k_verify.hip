@@ -1274,15 +1274,15 @@ __device__ inline uint32_t clamp_codes4(uint32_t x) {
     const uint32_t t = x & 0x04040404u;
     return t | (x & 0x03030303u & ~((t >> 1) | (t >> 2)));
 }
-// the same for the SW-semantics bound (k_edit_myers in bound mode): N stays N (it matches a read N, ssw/src/lib.rs:11-16),
-// everything above ('$', padding) becomes 5 = matches nothing
-__device__ inline uint32_t clamp_codes6(uint32_t x) {
+// the same under the SW matrix's matches (ssw/src/lib.rs:11-16: a window N matches a read N): N becomes 5, the row of the
+// match table that holds the read's N positions; everything above ('$', padding) 4 = matches nothing, as in clamp_codes4
+__device__ inline uint32_t clamp_codes_sw(uint32_t x) {
     const uint32_t t = x & 0x04040404u, lo = x & 0x03030303u;
     const uint32_t nz = (lo | (lo >> 1)) & 0x01010101u, m = t >> 2;
-    return t | (lo & ~(m * 3u)) | (nz & m);
+    return t | (lo & ~(m * 3u)) | ((nz ^ 0x01010101u) & m);
 }
-template <bool KEEP_N = false>
-__device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint32_t end, uint32_t strand, uint32_t j0) {
+// sw_matches: clamp for the SW matrix's matches (k_edit_myers bounding the prefilter) instead of the edit distance's
+__device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint32_t end, uint32_t strand, uint32_t j0, bool sw_matches) {
     uint4 r;
     if (!strand) {
         r = load16(ix.text, ix.n, start + j0);
@@ -1300,10 +1300,10 @@ __device__ inline uint4 fetch_cols(const DevIndexView& ix, uint32_t start, uint3
         }
         r = make_uint4(w[0], w[1], w[2], w[3]);
     }
-    r.x = KEEP_N ? clamp_codes6(r.x) : clamp_codes4(r.x);
-    r.y = KEEP_N ? clamp_codes6(r.y) : clamp_codes4(r.y);
-    r.z = KEEP_N ? clamp_codes6(r.z) : clamp_codes4(r.z);
-    r.w = KEEP_N ? clamp_codes6(r.w) : clamp_codes4(r.w);
+    r.x = sw_matches ? clamp_codes_sw(r.x) : clamp_codes4(r.x);
+    r.y = sw_matches ? clamp_codes_sw(r.y) : clamp_codes4(r.y);
+    r.z = sw_matches ? clamp_codes_sw(r.z) : clamp_codes4(r.z);
+    r.w = sw_matches ? clamp_codes_sw(r.w) : clamp_codes4(r.w);
     return r;
 }
 
@@ -1344,7 +1344,9 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     // align.rs:28-85 right under the read's first base, and the running score is simply the carry out
     // of the last word.
     constexpr bool LIST = MODE == MY_LIST, BOUND = MODE == MY_BOUND;
-    constexpr int NROW = BOUND ? 6 : 5;  // bound mode: N is a symbol of its own, row 5 = matches nothing
+    // rows 0-3: the bases; 4: matches nothing; 5 (bound and list mode): the read's N positions, which a window N matches in
+    // the SW matrix
+    constexpr int NROW = (BOUND || LIST) ? 6 : 5;
     __shared__ uint32_t eq_tab[NROW][W][256];
     const uint32_t tid = threadIdx.x;
     const uint32_t n_work = *a.wl_count;
@@ -1362,6 +1364,11 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
     uint32_t g = 0, o = 0, L = 0, ED = 0, strand = 0;
     bool thr_wrapped = false, hopeless = false;
     uint32_t pv0[W];  // vertical +1 deltas of column 0: the read's rows only
+    // list mode: what the lane is doing with candidate g.  0: the listed candidate's edit distance.  A candidate that fails it
+    // hands on to its TaxId's next candidate (index.rs:393), which the same lane then decides: 1: that candidate's prefilter
+    // by the edit-distance bound (as in bound mode), 2: its edit distance once the bound has passed it (reads with N only:
+    // without N the two distances are the same number).  Only a successor the bound leaves undecided goes to another round.
+    uint32_t ph = 0, read_n = 0, extra_passed = 0;
     for (;;) {
         unsigned long long need = __ballot(!active);
         if (need) {
@@ -1440,13 +1447,15 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     eq_tab[1][k][tid] = (strand ? mG : mC) | wild;
                     eq_tab[2][k][tid] = (strand ? mC : mG) | wild;
                     eq_tab[3][k][tid] = (strand ? mA : mT) | wild;
+                    eq_tab[4][k][tid] = wild;
                     // every read position that is no base is an N (k_normalise): it matches a window N in the SW matrix only
-                    eq_tab[4][k][tid] = BOUND ? ~(mA | mC | mG | mT) : wild;
-                    if (BOUND) eq_tab[NROW - 1][k][tid] = wild;
+                    if (NROW == 6) eq_tab[5][k][tid] = ~(mA | mC | mG | mT);
                     pv0[k] = ~wild;
                 }
                 // edits >= number of read positions that match nothing (N): see k_evaluate
                 hopeless = thr_wrapped || (!BOUND && L - matchable > ED);
+                read_n = L - matchable;
+                ph = 0;
                 active = true;
             }
             bnext = min(bnext + (uint32_t)__popcll(need), bend);
@@ -1479,16 +1488,17 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             int score = (int)L, best = (int)L;  // D[L][0] = L
             // The window's columns arrive 16 at a time, one fetch ahead of the recurrence (three ahead measured the same and
             // cost eight registers: a wavefront of occupancy here)
-            uint4 nxt4 = Wn ? fetch_cols<BOUND>(ix, c.x, c.y, strand, 0) : make_uint4(0, 0, 0, 0);
+            const bool swm = BOUND || (LIST && ph == 1);  // matches of the SW matrix, early exits of the bound
+            uint4 nxt4 = Wn ? fetch_cols(ix, c.x, c.y, strand, 0, swm) : make_uint4(0, 0, 0, 0);
             const uint32_t* lane_tab = &eq_tab[0][0][tid];
             uint32_t j0 = 0;
             for (; j0 < Wn; j0 += 16) {
-                if (BOUND) {  // decided already: passes, or the last row cannot come down to 2*ED any more
-                    if (best <= (int)ED) break;
+                if (swm) {  // decided already: passes, or the last row cannot come down to 2*ED any more
+                    if (BOUND && best <= (int)ED) break;  // (list mode goes on: its minimum is the edit distance of a read without N)
                     if (best > 2 * (int)ED && score - (int)(Wn - j0) > 2 * (int)ED) break;
                 }
                 const uint4 cur = nxt4;
-                if (j0 + 16 < Wn) nxt4 = fetch_cols<BOUND>(ix, c.x, c.y, strand, j0 + 16);  // prefetch the next 16 columns
+                if (j0 + 16 < Wn) nxt4 = fetch_cols(ix, c.x, c.y, strand, j0 + 16, swm);  // prefetch the next 16 columns
                 const uint32_t lim = min(16u, Wn - j0);
 #pragma unroll
                 for (int jj = 0; jj < 16; jj++) {
@@ -1522,7 +1532,7 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                 }
             }
             cols += min(j0, Wn);
-            if (!LIST && (!BOUND || !counted)) {
+            if (LIST ? ph == 1 : (!BOUND || !counted)) {  // (list mode: a successor is counted where its prefilter runs)
                 verified++;
                 wbytes += Wn;
             }
@@ -1544,6 +1554,26 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                     if (nxt == 0xffffffffu || nxt >= maxc) active = false;
                     else g = o + nxt;
                 }
+            } else if (LIST && ph == 1) {  // a successor's prefilter, decided by the bound
+                if (ed > 2 * ED) {  // refuted (index.rs:406)
+                    a.cand_status[g] = 1;
+                    const uint32_t nxt = a.cand_next[g];
+                    if (nxt == 0xffffffffu || nxt >= maxc) active = false;
+                    else g = o + nxt;
+                } else if (ed > ED) {  // neither bound decides: the sweep of the next round does (counted here: flagged)
+                    a.next_list[atomicAdd(a.next_count, 1u)] = g | kSweepFlag;
+                    active = false;
+                } else {  // passes the prefilter; without N in the read this number is its edit distance too
+                    extra_passed++;
+                    if (read_n == 0) {
+                        const DevBin bin = ix.bins[c.z];
+                        a.out[g] = make_uint4(bin.tax_id, bin.gi, c.x >= bin.start ? c.x - bin.start : 0, ed);
+                        a.cand_status[g] = 2;
+                        active = false;
+                    } else {
+                        ph = 2;
+                    }
+                }
             } else {
             const bool pass = !thr_wrapped && ed <= ED;
             if (pass) {
@@ -1555,10 +1585,10 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
                 a.cand_status[g] = 1;
                 const uint32_t nxt = a.cand_next[g];
                 if (nxt == 0xffffffffu || nxt >= maxc) active = false;
-                else if (LIST) {  // rare: passed the prefilter, failed the edit distance
-                    a.next_list[atomicAdd(a.next_count, 1u)] = o + nxt;
-                    active = false;
-                } else g = o + nxt;
+                else {
+                    g = o + nxt;
+                    if (LIST) ph = 1;  // passed the prefilter, failed the edit distance (rare): the TaxId's next candidate, here
+                }
             }
             }
         }
@@ -1593,9 +1623,12 @@ __global__ __launch_bounds__(256) void k_edit_myers(DevIndexView ix, EvalArgs a)
             c64 += __shfl_down(c64, d);
             r64 += __shfl_down(r64, d);
         }
+        unsigned long long e64 = extra_passed;
+        for (int d = 32; d > 0; d >>= 1) e64 += __shfl_down(e64, d);
         if (lane == 0) {
             atomicAdd(a.myers_ctr, c64);
             if (BOUND && r64) atomicAdd(a.myers_ctr + 1, r64);
+            if (LIST && e64) atomicAdd(a.myers_ctr + 2, e64);
         }
     }
 }

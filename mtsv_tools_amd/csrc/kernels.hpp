@@ -68,7 +68,8 @@ struct EvalArgs {
     uint32_t* pass_count = nullptr;
     uint32_t* next_list = nullptr;
     uint32_t* next_count = nullptr;
-    unsigned long long* myers_ctr = nullptr;  // k_edit_myers: [0] += columns its recurrences advanced, [1] += candidates its bound refuted
+    unsigned long long* myers_ctr = nullptr;  // k_edit_myers: [0] += columns its recurrences advanced, [1] += candidates its bound refuted,
+                                              // [2] += successors the list mode's own bound passed (they count as sent on to the edit distance)
     uint32_t* und_list = nullptr;  // k_sw_pairs TOP / k_edit_myers bound mode: candidates they do not decide
     uint32_t und_slot = 0;
     // tiled long-read kernel: one strip of strip_len window columns per 16-lane group (bottom row of a band)

@@ -22,8 +22,11 @@ timeout -k 10 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv 
 echo "write done"
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES --output-format csv -d $OUT/sq -o p -- python3 $ROOT/bench.py --workload $WL --steps 1 --warmup 0 --resident-only > /dev/null 2> $OUT/sq.err
 echo "sq done"
+timeout -k 10 600 rocprofv3 --kernel-trace --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum --output-format csv -d $OUT/tlb -o p -- python3 $ROOT/bench.py --workload $WL --steps 1 --warmup 0 --resident-only > /dev/null 2> $OUT/tlb.err
+echo "tlb done"
 cd $ROOT
 python3 tools/profile_summary.py trace $OUT/trace $OUT/kernel_stats.csv
 python3 tools/profile_summary.py pmc $OUT/fetch $OUT/write $WL $OUT/hbm_pmc.json $OUT/hbm_traffic.json
 python3 tools/profile_summary.py sq $OUT/sq $OUT/trace $OUT/sq_counters.txt $OUT/hbm_traffic.json
-rm -rf $OUT/fetch $OUT/write $OUT/sq   # raw counter CSVs are large
+python3 tools/profile_summary.py tlb $OUT/tlb $OUT/tlb_counters.txt
+rm -rf $OUT/fetch $OUT/write $OUT/sq $OUT/tlb   # raw counter CSVs are large

@@ -113,8 +113,31 @@ def sq(dsq, dtrace, out, traffic=None):
         json.dump(t, open(traffic, "w"), indent=1)
 
 
+def tlb(dtlb, out):
+    """TCP_UTCL1 (the per-CU first-level address translation cache) requests / hits / misses per pipeline kernel, one pass"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(float))
+    for r in csv.DictReader(open(find(dtlb, "counter_collection.csv"))):
+        acc[norm(r["Kernel_Name"])][r["Counter_Name"]] += float(r["Counter_Value"])
+    dur = collections.defaultdict(float)
+    for r in csv.DictReader(open(find(dtlb, "kernel_trace.csv"))):
+        dur[norm(r["Kernel_Name"])] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+    with open(out, "w") as f:
+        f.write("MTSV_LANES=1 rocprofv3 --kernel-trace --pmc TCP_UTCL1_REQUEST_sum TCP_UTCL1_TRANSLATION_HIT_sum TCP_UTCL1_TRANSLATION_MISS_sum\n"
+                "  -- python3 bench.py --steps 1 --warmup 0 --resident-only     (one whole-batch pipeline pass; commit " + COMMIT + ")\n")
+        for k in sorted(dur, key=lambda k: -dur[k]):
+            if not k.startswith("k_") or k in ("k_expand_sa", "k_kmer_level", "k_kmer_level1"):
+                continue
+            c = acc[k]
+            req, hit, miss = c.get("TCP_UTCL1_REQUEST_sum", 0.0), c.get("TCP_UTCL1_TRANSLATION_HIT_sum", 0.0), c.get("TCP_UTCL1_TRANSLATION_MISS_sum", 0.0)
+            f.write(f"{k:28s} {dur[k]:7.2f} ms  UTCL1 requests {req:.3g}  hits {hit:.3g}  misses {miss:.3g}  miss ratio {miss / req if req else float('nan'):.3f}  "
+                    f"misses per us {miss / (dur[k] * 1e3) if dur[k] else 0:.0f}\n")
+    print("wrote", out)
+
+
 if __name__ == "__main__":
-    if sys.argv[1] == "trace":
+    if sys.argv[1] == "tlb":
+        tlb(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "trace":
         trace(sys.argv[2], sys.argv[3])
     elif sys.argv[1] == "sq":
         sq(*sys.argv[2:6])
