@@ -129,7 +129,7 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     dev_alloc(&d_strand_off, ns + 1, &bytes);
     dev_alloc(&d_strand_ncand, ns, &bytes);
     dev_alloc(&d_strand_nout, ns + 1, &bytes);
-    dev_alloc(&d_heavy_list, ns, &bytes);
+    dev_alloc(&d_heavy_list, 2 * ns, &bytes);  // [0, ns): the two strand lists of the coalescing kernels (front / back), [ns, 2 ns): the 13..16-hit strands
     dev_alloc(&d_out_off, ns + 1, &bytes);
     dev_alloc(&d_tile_sums, (uint64_t)scan_tiles((uint32_t)ns) + 1, &bytes);
     dev_alloc(&d_counters, kCounters, &bytes);
@@ -512,7 +512,7 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         // counters: [1] lo = round-0 worklist count, [7] lo/hi = ping-pong counts of later rounds
         HIP_CHECK(hipMemsetAsync(d_counters + 1, 0, 8, stream));
         HIP_CHECK(hipMemsetAsync(d_counters + 7, 0, 8, stream));
-        HIP_CHECK(hipMemsetAsync(d_counters + 15, 0, 8, stream));  // [15] lo = strands of 17..64 seed hits
+        HIP_CHECK(hipMemsetAsync(d_counters + 15, 0, 8, stream));  // [15] lo = strands for k_coalesce_mid, hi = strands of 13..16 seed hits
         launch_coalesce(stream, v, so, (uint32_t)r0, nstr, p.max_candidates, d_strand_off,
                         d_strand_nseeds, d_hit_ref, d_hit_q, d_hit_key, d_cand_tmp, d_cand, d_cand_next,
                         d_cand_status, d_strand_ncand, d_worklist, d_heavy_list, d_counters);

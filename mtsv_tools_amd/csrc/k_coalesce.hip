@@ -336,6 +336,7 @@ struct CoalesceArgs {
 // slots of the counter block (batch.hip's d_counters) the coalescing kernels use
 __device__ inline uint32_t* co_wl_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 1); }
 __device__ inline uint32_t* co_heavy_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 1) + 1; }
+__device__ inline uint32_t* co_lane16_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 15) + 1; }
 __device__ inline uint32_t* co_mid_count(const CoalesceArgs& a) { return reinterpret_cast<uint32_t*>(a.counters + 15); }
 __device__ inline unsigned long long* co_n_cand(const CoalesceArgs& a) { return reinterpret_cast<unsigned long long*>(a.counters + 3); }
 
@@ -351,7 +352,7 @@ __device__ inline unsigned long long* co_n_cand(const CoalesceArgs& a) { return 
 // Everything a wavefront appends to a shared list -- work items, the strands it passes on -- is buffered in LDS and
 // appended with one atomic per few hundred entries: a returning atomic on one address completes at ~11 ns, and one per
 // 64 strands (312 k of them for 10 M reads) had been a floor of 3.4 ms under this kernel whatever its instructions.
-constexpr int kLaneHits = 12, kLaneCands = 4;
+constexpr int kLaneHitsFirst = 12, kLaneHitsSecond = 16, kLaneCands = 4;
 constexpr uint32_t kPendCap = 768, kPendFlush = 512;  // work items a wavefront buffers in LDS; flushed with one atomic beyond kPendFlush
 constexpr uint32_t kMidCap = 256, kMidFlush = 192;    // strands for k_coalesce_mid, likewise
 constexpr uint32_t kHeavyCap = 128, kHeavyFlush = 64;  // ... and for k_coalesce_heavy
@@ -364,12 +365,29 @@ constexpr uint32_t kHeavyCap = 128, kHeavyFlush = 64;  // ... and for k_coalesce
     CX(4, 8) CX(2, 10) CX(6, 10) CX(2, 4) CX(6, 8) CX(1, 9) CX(5, 9) CX(3, 11) CX(7, 11) CX(3, 5) CX(7, 9) CX(1, 2)       \
     CX(3, 4) CX(5, 6) CX(7, 8) CX(9, 10)
 
+// the whole network for 16 keys: 63 comparators
+#define MTSV_SORT16(CX) \
+    CX(0, 1) CX(2, 3) CX(0, 2) CX(1, 3) CX(1, 2) CX(4, 5) CX(6, 7) CX(4, 6) CX(5, 7) CX(5, 6) CX(0, 4) CX(2, 6) \
+    CX(2, 4) CX(1, 5) CX(3, 7) CX(3, 5) CX(1, 2) CX(3, 4) CX(5, 6) CX(8, 9) CX(10, 11) CX(8, 10) CX(9, 11) CX(9, 10) \
+    CX(12, 13) CX(14, 15) CX(12, 14) CX(13, 15) CX(13, 14) CX(8, 12) CX(10, 14) CX(10, 12) CX(9, 13) CX(11, 15) \
+    CX(11, 13) CX(9, 10) CX(11, 12) CX(13, 14) CX(0, 8) CX(4, 12) CX(4, 8) CX(2, 10) CX(6, 14) CX(6, 10) CX(2, 4) \
+    CX(6, 8) CX(10, 12) CX(1, 9) CX(5, 13) CX(5, 9) CX(3, 11) CX(7, 15) CX(7, 11) CX(3, 5) CX(7, 9) CX(11, 13) CX(1, \
+    2) CX(3, 4) CX(5, 6) CX(7, 8) CX(9, 10) CX(11, 12) CX(13, 14)
+
+// HITS = 12, LISTED = false: the pass over all strands.  HITS = 16, LISTED = true: the strands of 13..16 seed hits the first
+// pass put on a list of their own (a read's origin plus a few chance hits, or the edge of a second origin): a lane each
+// as well, instead of a wavefront each in k_coalesce_mid.
+template <int HITS, bool LISTED>
 __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs a) {
     __shared__ uint32_t pend_all[256 / kWave][kPendCap];
     __shared__ uint32_t mid_all[256 / kWave][kMidCap];
+    __shared__ uint32_t second_all[LISTED ? 1 : 256 / kWave][LISTED ? 1 : kMidCap];
+    __shared__ uint64_t walk_keys[LISTED ? HITS : 1][LISTED ? 256 : 1];
     __shared__ uint32_t heavy_all[256 / kWave][kHeavyCap];
     uint32_t* pend_buf = pend_all[threadIdx.x / kWave];
     uint32_t* mid_buf = mid_all[threadIdx.x / kWave];
+    uint32_t* second_buf = second_all[LISTED ? 0 : threadIdx.x / kWave];
+    uint32_t n_second = 0;
     uint32_t* heavy_buf = heavy_all[threadIdx.x / kWave];
     const uint32_t lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) / kWave;
@@ -387,6 +405,15 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
         for (uint32_t i = lane; i < pend; i += kWave) a.worklist[base + i] = pend_buf[i];
         wave_mem_sync();
         pend = 0;
+    };
+    auto flush_second = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(co_lane16_count(a), n_second);
+        base = __builtin_amdgcn_readfirstlane(base);
+        wave_mem_sync();
+        for (uint32_t i = lane; i < n_second; i += kWave) a.heavy_list[a.n_strands + base + i] = second_buf[i];
+        wave_mem_sync();
+        n_second = 0;
     };
     auto flush_mid = [&]() {  // front of the strand list: k_coalesce_mid
         uint32_t base = 0;
@@ -406,26 +433,28 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
         wave_mem_sync();
         n_heavy = 0;
     };
-    for (uint32_t base64 = wave * kWave; base64 < a.n_strands; base64 += n_waves * kWave) {
-        const uint32_t rs = base64 + lane;
-        const bool valid = rs < a.n_strands;
+    const uint32_t n_items = LISTED ? *co_lane16_count(a) : a.n_strands;
+    for (uint32_t base64 = wave * kWave; base64 < n_items; base64 += n_waves * kWave) {
+        const bool valid = base64 + lane < n_items;
+        const uint32_t rs = LISTED ? (valid ? a.heavy_list[a.n_strands + base64 + lane] : 0u) : base64 + lane;
         const uint32_t o = valid ? a.strand_off[rs] : 0;
         const uint32_t nh = valid ? a.strand_off[rs + 1] - o : 0;
-        if (valid && nh == 0) a.strand_ncand[rs] = 0;
-        bool to_mid = nh > (uint32_t)kLaneHits && nh <= (uint32_t)kWave;
+        if (!LISTED && valid && nh == 0) a.strand_ncand[rs] = 0;
+        const bool to_second = !LISTED && nh > (uint32_t)HITS && nh <= (uint32_t)kLaneHitsSecond;
+        bool to_mid = nh > (uint32_t)(LISTED ? HITS : kLaneHitsSecond) && nh <= (uint32_t)kWave;
         const bool heavy = nh > (uint32_t)kWave;
         uint32_t gnc = 0;
         uint32_t cs[kLaneCands], ce[kLaneCands], cb[kLaneCands], cn[kLaneCands], ct[kLaneCands];
 #pragma unroll
         for (int k = 0; k < kLaneCands; k++) cs[k] = ce[k] = cb[k] = cn[k] = ct[k] = 0;
         bool hopeless = false;
-        if (nh >= 1 && nh <= (uint32_t)kLaneHits) {
+        if (nh >= 1 && nh <= (uint32_t)HITS) {
             const uint32_t ns_raw = a.strand_nseeds[rs];
             hopeless = (ns_raw & kHopeless) != 0;  // k_thin's flag (see kHopeless)
             const StrandGeom gg = strand_geom(a.read_off, r0 + (rs >> 1), ns_raw);
-            uint64_t key[kLaneHits];
+            uint64_t key[HITS];
 #pragma unroll
-            for (int i = 0; i < kLaneHits; i++)
+            for (int i = 0; i < HITS; i++)
                 key[i] = (uint32_t)i < nh ? ((uint64_t)a.hit_ref[o + i] << 32) | a.hit_q[o + i] : ~0ull;
             // seed_hits.sort(): (reference_offset, query_offset), index.rs:443
 #define MTSV_CX(I, J)                      \
@@ -434,7 +463,11 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
         key[I] = lo_;                      \
         key[J] = hi_;                      \
     }
-            MTSV_SORT12(MTSV_CX)
+            if (HITS == 12) {
+                MTSV_SORT12(MTSV_CX)
+            } else {
+                MTSV_SORT16(MTSV_CX)
+            }
 #undef MTSV_CX
             // the walk of index.rs:445-485
             bool have = false;
@@ -455,10 +488,14 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
                     gnc++;
                 }
             };
+            // (the second pass walks its sixteen keys in a rolled loop out of LDS: unrolled sixteen times the walk does not fit
+            //  the scalar register file)
+            if (LISTED) {
 #pragma unroll
-            for (int i = 0; i < kLaneHits; i++) {
-                if ((uint32_t)i < nh) {
-                    const uint32_t site = (uint32_t)(key[i] >> 32), q = (uint32_t)key[i];
+                for (int i = 0; i < HITS; i++) walk_keys[LISTED ? i : 0][LISTED ? threadIdx.x : 0] = key[i];
+            }
+            auto walk_step = [&](uint64_t key_i) {
+                    const uint32_t site = (uint32_t)(key_i >> 32), q = (uint32_t)key_i;
                     // first bin whose end > site (index.rs:455-458): the sites ascend, so it only changes when they pass its end
                     if (cur_b == 0xffffffffu || site >= cur.end) {
                         cur_b = min(find_bin(ix, site), ix.n_bins - 1);
@@ -480,7 +517,14 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
                         w_n = 1;
                         w_t = cur.tax_id;
                     }
-                }
+            };
+            if (LISTED) {
+#pragma unroll 1
+                for (uint32_t i = 0; i < nh; i++) walk_step(walk_keys[LISTED ? i : 0][LISTED ? threadIdx.x : 0]);
+            } else {
+#pragma unroll
+                for (int i = 0; i < HITS; i++)
+                    if ((uint32_t)i < nh) walk_step(key[i]);
             }
             flush();  // index.rs:481-485
             if (gnc > (uint32_t)kLaneCands) {  // more candidates than the registers hold: k_coalesce_mid does this strand
@@ -490,6 +534,14 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
         }
         {   // the longer strands: 13..64 hits (and the rare overflow above) for k_coalesce_mid, > 64 for k_coalesce_heavy
             const unsigned long long bm = __ballot(to_mid), bh = __ballot(heavy);
+            if (!LISTED) {  // 13..16 hits: the list of the second lane pass (behind the n_strands entries of the other two lists)
+                const unsigned long long bs = __ballot(to_second);
+                if (bs) {
+                    if (to_second) second_buf[n_second + __popcll(bs & ((1ull << lane) - 1))] = rs;
+                    n_second += (uint32_t)__popcll(bs);
+                    if (n_second > kMidFlush) flush_second();
+                }
+            }
             if (bm) {
                 if (to_mid) mid_buf[n_mid + __popcll(bm & ((1ull << lane) - 1))] = rs;
                 n_mid += (uint32_t)__popcll(bm);
@@ -501,7 +553,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
                 if (n_heavy > kHeavyFlush) flush_heavy();
             }
         }
-        const bool mine = nh >= 1 && nh <= (uint32_t)kLaneHits && !to_mid;  // this lane finishes its strand here
+        const bool mine = nh >= 1 && nh <= (uint32_t)HITS && !to_mid;  // this lane finishes its strand here
         // stable sort by num_seeds descending (index.rs:369) as a rank; the same-TaxId chain in rank order: a candidate is
         // verified only after every earlier candidate of its TaxId has failed (index.rs:393), so only the first of each
         // TaxId starts as work
@@ -568,6 +620,7 @@ __global__ __launch_bounds__(256) void k_coalesce(DevIndexView ix, CoalesceArgs 
     }
     if (pend) flush_pend();
     if (n_mid) flush_mid();
+    if (!LISTED && n_second) flush_second();
     if (n_heavy) flush_heavy();
     for (int d = 32; d > 0; d >>= 1) {
         cand_sum += __shfl_down(cand_sum, d);
@@ -736,7 +789,9 @@ void launch_coalesce(hipStream_t s, const DevIndexView& ix, const uint32_t* read
     c.worklist = worklist;
     c.heavy_list = heavy_list;
     c.counters = counters;
-    hipLaunchKernelGGL(k_coalesce, dim3(blocks), dim3(256), 0, s, ix, c);
+    hipLaunchKernelGGL((k_coalesce<kLaneHitsFirst, false>), dim3(blocks), dim3(256), 0, s, ix, c);
+    // the 13..16-hit strands it listed (a few percent of the strands: a modest grid strides over the device-side count)
+    hipLaunchKernelGGL((k_coalesce<kLaneHitsSecond, true>), dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 8192, 8), 512)), dim3(256), 0, s, ix, c);
     // the list of longer strands is short (device-side count): a modest grid of wavefronts walks it
     hipLaunchKernelGGL(k_coalesce_mid, dim3(std::min<uint32_t>(std::max<uint32_t>(n_strands / 2048, std::min<uint32_t>(std::max<uint32_t>(n_strands / 256, 1), 128)), 1024)), dim3(256), 0, s, ix, c);
     HeavyArgs a;
