@@ -659,6 +659,14 @@ int main(int argc, char** argv) {
     };
     std::atomic<uint64_t> t_ingest_wait{0}, t_push_wait{0}, t_gpu{0}, t_gpu_wait{0}, t_fmt{0}, t_done_wait{0}, t_write_wait{0};
     auto acc = [](std::atomic<uint64_t>& a, double s) { a.fetch_add((uint64_t)(s * 1e6)); };
+    const double t_begin = now();
+    std::mutex marks_mu;
+    std::vector<std::pair<std::string, double>> marks;  // (what, seconds since the queries began), printed with the timing
+    auto mark = [&](const std::string& what) {
+        if (!cli_timing) return;
+        std::lock_guard<std::mutex> lk(marks_mu);
+        marks.emplace_back(what, now() - t_begin);
+    };
 
     // Overlapped stages (the reference overlaps producer / workers / joiner the same way,
     // vendor/cue/src/lib.rs:45-105): the producer parses FASTX into numbered batches, GPU workers (one per
@@ -736,6 +744,7 @@ int main(int argc, char** argv) {
             w->rb = std::move(rb);
             w->seq = n_batches++;
             const double t_a = now();
+            if (w->seq == 0) mark("first block parsed");
             acc(t_ingest_wait, t_a - t_last);  // producing this batch (mostly: waiting for the parser threads)
             parsed.push(std::move(w));
             t_last = now();
@@ -746,6 +755,7 @@ int main(int argc, char** argv) {
             logmsg("ERROR", "Unable to read from input file: " + rd.err_msg);
             set_code(12);  // binner.rs:81-84
         }
+        mark("last block parsed");
         parsed.close();
     });
 
@@ -950,6 +960,12 @@ int main(int argc, char** argv) {
                 continue;
             }
             acc(t_gpu, now() - t_g);
+            if (cli_timing) {
+                char what[96];
+                snprintf(what, sizeof what, "worker %zu: call on %llu reads in %zu blocks took %.2f ms, ended", wk, (unsigned long long)group_reads,
+                         group.size(), (now() - t_g) * 1e3);
+                mark(what);
+            }
             // every batch gets its slice of the hits, read numbers relative to the batch
             std::shared_ptr<void> owner(hits, [](void* q) { mtsv_hits_free((mtsv_hit*)q); });
             uint64_t first = 0, at = 0;
@@ -967,7 +983,9 @@ int main(int argc, char** argv) {
             }
             for (auto& w : group) done.push(std::move(w));
         }
+        mark("worker out of batches");
         if (ws) mtsv_batch_free(ws);
+        mark("worker's workspace freed");
     };
     {
         std::vector<std::thread> workers;
@@ -978,6 +996,7 @@ int main(int argc, char** argv) {
     done.close();
     reader.join();
     writer.join();
+    mark("writer done");
     if (exit_code) return exit_code;
     if (::close(out_fd) != 0) {
         logmsg("ERROR", "Error writing to result file");
@@ -994,6 +1013,8 @@ int main(int argc, char** argv) {
                         "writer: formatting %.3f s, waiting for hits %.3f s, waiting for the disk %.3f s\n",
                 (unsigned long long)n_batches, t_ingest_wait.load() * 1e-6, t_push_wait.load() * 1e-6, t_gpu.load() * 1e-6, t_gpu_wait.load() * 1e-6,
                 t_fmt.load() * 1e-6, t_done_wait.load() * 1e-6, t_write_wait.load() * 1e-6);
+    if (cli_timing && getenv("MTSV_CLI_MARKS"))
+        for (auto& m : marks) fprintf(stderr, "[cli timing] %9.3f ms  %s\n", m.second * 1e3, m.first.c_str());
     for (auto* ix : idx) mtsv_index_free(ix);
     return 0;
 }

@@ -60,6 +60,7 @@ for br in ("65536", "131072", "262144", "524288"):
 run("/tmp/cli.fastq", ["--batch-reads", "131072"], env={"MTSV_CLI_GROUP_READS": "2097152"})
 run("/tmp/cli.fastq", ["--batch-reads", "65536"], env={"MTSV_CLI_GROUP_READS": "2097152"})
 run("/tmp/cli.fastq")
+run("/tmp/cli.fastq", env={"MTSV_CLI_MARKS": "1"})   # the same with the time line of the run on stderr
 run("/tmp/cli.fastq", ["--batch-reads", "262144"], env={"MTSV_CLI_PAGEABLE": "1"})
 run("/tmp/cli.fastq", ["--devices", "0,0"])
 run("/tmp/cli.fastq", ["--devices", "0,0,0"])
