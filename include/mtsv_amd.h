@@ -189,6 +189,17 @@ uint64_t mtsv_bin_batch_workspace_reads(uint64_t n_reads);
  * on `hip_device`.  max_hits_ws = seed-hit workspace entries (0 = default). */
 int mtsv_batch_create(mtsv_index *ix, int hip_device, uint64_t max_reads, uint64_t max_bases,
                       uint64_t max_hits_ws, mtsv_batch **out);
+/* The same with the number of LANES chosen: a host batch (mtsv_batch_run_host*) is worked off in ranges, `lanes` of them
+ * at a time, each on a stream and a set of work arrays of its own (0: the default, three).  A host that keeps several
+ * calls in flight on one device -- a workspace per worker thread, as mtsv-binner does -- asks for one lane each: its
+ * calls are what overlap.  (No counterpart in the reference: src/binner.rs:57-76 is a pool of CPU threads.) */
+int mtsv_batch_create_lanes(mtsv_index *ix, int hip_device, uint64_t max_reads, uint64_t max_bases,
+                            uint64_t max_hits_ws, int lanes, mtsv_batch **out);
+/* Make the workspace ready for host batches of up to n_reads reads / n_bases bases: what mtsv_batch_run_host* would
+ * otherwise size on its first calls (device arenas, the page-locked offset table, a result array) is created now, and
+ * with warm_read_len > 0 a small batch of reads of that length sampled from the index runs through every kernel (the
+ * first launch of a kernel loads its code object).  Part of the device set-up, like mtsv_index_to_device. */
+int mtsv_batch_reserve_host(mtsv_batch *b, uint64_t n_reads, uint64_t n_bases, uint32_t warm_read_len);
 /* Order in which the two acceptance predicates of index.rs:406,410 are evaluated (results identical):
  *   MTSV_VERIFY_REFERENCE   SW prefilter score and edit distance for every verified candidate (default)
  *   MTSV_VERIFY_EDIT_FIRST  edit distance first; for reads <= 253 bases edits <= ED implies the SW

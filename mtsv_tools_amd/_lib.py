@@ -66,6 +66,7 @@ EXPORTS = [
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads", "mtsv_bin_batch_workspace_reads",
     "mtsv_bin_batch_multi", "mtsv_bin_batch_chunks", "mtsv_set_default_verify_mode",
     "mtsv_host_alloc", "mtsv_host_free", "mtsv_host_register", "mtsv_host_unregister",
+    "mtsv_batch_create_lanes", "mtsv_batch_reserve_host",
 ]
 
 _lib = None
@@ -101,6 +102,8 @@ def lib():
         L.mtsv_bin_batch_workspace_reads.argtypes = [u64]
         L.mtsv_bin_batch_workspace_reads.restype = u64
         L.mtsv_batch_create.argtypes = [vp, i32, u64, u64, u64, C.POINTER(vp)]
+        L.mtsv_batch_create_lanes.argtypes = [vp, i32, u64, u64, u64, i32, C.POINTER(vp)]
+        L.mtsv_batch_reserve_host.argtypes = [vp, u64, u64, u32]
         L.mtsv_batch_upload.argtypes = [vp, vp, vp, u64]
         L.mtsv_batch_run.argtypes = [vp, C.POINTER(Params)]
         L.mtsv_batch_run_host.argtypes = [vp, vp, vp, u64, C.POINTER(Params)]
@@ -296,11 +299,16 @@ class MGIndex:
 class Batch:
     """Owning handle of an mtsv_batch (HBM-resident read batch + workspace)."""
 
-    def __init__(self, index, device, max_reads, max_bases, max_hits_ws=0):
+    def __init__(self, index, device, max_reads, max_bases, max_hits_ws=0, lanes=0):
         self.index = index
         self.h = C.c_void_p()
-        _check(lib().mtsv_batch_create(index.h, device, max_reads, max_bases, max_hits_ws,
-                                       C.byref(self.h)))
+        _check(lib().mtsv_batch_create_lanes(index.h, device, max_reads, max_bases, max_hits_ws, lanes,
+                                             C.byref(self.h)))
+
+    def reserve_host(self, n_reads, n_bases, warm_read_len=0):
+        """mtsv_batch_reserve_host: size what run_host would size on its first calls; warm_read_len > 0 also runs a
+        small batch sampled from the index through every kernel"""
+        _check(lib().mtsv_batch_reserve_host(self.h, n_reads, n_bases, warm_read_len))
 
     def upload(self, bases, read_off):
         bases = np.ascontiguousarray(bases, dtype=np.uint8)

@@ -95,7 +95,7 @@ int g_default_verify_mode = MTSV_VERIFY_REFERENCE;
 constexpr uint64_t kLaneMinReads = 32768;  // a lane below this many reads does not fill the device
 constexpr uint64_t kChunkMaxReads = 4ull << 20;  // lanes take a range in chunks of at most this many reads (smaller chunks measured slower: per-pass launches and host round trips)
 
-Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t max_bases_, uint64_t hit_cap_, Batch* parent_)
+Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t max_bases_, uint64_t hit_cap_, Batch* parent_, int lanes_)
     : ix(ix_), di(di_), max_reads(max_reads_), max_bases(max_bases_), hit_cap(hit_cap_), parent(parent_) {
     if (max_reads == 0) max_reads = 1;
     if (max_reads > 0x7fffffffull) throw std::runtime_error("limit: more than 2^31 reads in one batch");
@@ -103,7 +103,8 @@ Batch::Batch(mtsv_index* ix_, DeviceIndex* di_, uint64_t max_reads_, uint64_t ma
     const uint64_t hit_cap_user = hit_cap;
     if (!parent) {
         n_lanes = 3;
-        if (const char* e = getenv("MTSV_LANES")) n_lanes = std::max(1, std::min(8, atoi(e)));
+        if (lanes_ > 0) n_lanes = std::min(8, lanes_);
+        else if (const char* e = getenv("MTSV_LANES")) n_lanes = std::max(1, std::min(8, atoi(e)));
         if (max_reads < (uint64_t)n_lanes * kLaneMinReads) n_lanes = 1;
     }
     ws_reads = (max_reads + n_lanes - 1) / n_lanes;
@@ -819,12 +820,8 @@ void Batch::run_host(const uint8_t* bases, const uint64_t* read_off, uint64_t n,
 // The same for a batch that lies in several pieces (mtsv_batch_run_host_parts: a host that parses its input in blocks hands
 // several blocks to one call -- larger passes on the device -- without putting them together first).  The reads are
 // numbered through the parts in order.
-void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params& p, uint64_t read_base) {
-    const double t_entry = now_s();
-    HIP_CHECK(hipSetDevice(di->device));
-    std::vector<Batch*> ls{this};
-    for (auto& l : extra) ls.push_back(l.get());
-    const bool trace = getenv("MTSV_TRACE") != nullptr;
+// What run_host sizes by its batch: the copy streams, the device arenas, the page-locked offset table.
+void Batch::host_room(uint64_t n, uint64_t total_bases, bool trace) {
     if (!copy_stream) {
         // The copy streams get a priority of their own.  The runtime maps streams onto a few hardware queues (four by
         // default, GPU_MAX_HW_QUEUES) round robin, per priority; an asynchronous copy holds its queue with a barrier
@@ -835,6 +832,55 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
         HIP_CHECK(hipStreamCreateWithPriority(&copy_stream, hipStreamNonBlocking, prio_high));
         HIP_CHECK(hipStreamCreateWithPriority(&copy_stream2, hipStreamNonBlocking, prio_high));
     }
+    uint64_t arena_bases = kArenaBases, arena_reads = kArenaReads;
+    if (const char* e = getenv("MTSV_ARENA_BASES")) arena_bases = std::max<uint64_t>(1 << 16, strtoull(e, nullptr, 10));  // (tests)
+    const bool one_segment = total_bases <= arena_bases && n <= arena_reads;
+    {
+        const uint64_t want_b = one_segment ? total_bases : arena_bases, want_r = one_segment ? n : std::min(n, arena_reads);
+        for (int k = 0; k < (one_segment ? 1 : 2); k++) {
+            Arena& ar = arena[k];
+            if (ar.cap_bases < want_b || ar.cap_reads < want_r) {
+                if (trace) fprintf(stderr, "[run_host] arena %d: %.1f MB of bases, %llu reads\n", k, want_b / 1e6, (unsigned long long)want_r);
+                (void)hipFree(ar.d_bases);
+                (void)hipFree(ar.d_off);
+                ar.d_bases = nullptr;
+                ar.d_off = nullptr;
+                ar.cap_bases = ar.cap_reads = 0;
+                const uint64_t cb = want_b + want_b / 16, cr = want_r + want_r / 16;  // a little room: the next batch is rarely the same size
+                dev_alloc(&ar.d_bases, std::min(cb, arena_bases) + 64, &bytes);  // k_search reads up to 36 bytes past a seed start
+                dev_alloc(&ar.d_off, std::min(cr, arena_reads) + 1, &bytes);
+                ar.cap_bases = std::min(cb, arena_bases);
+                ar.cap_reads = std::min(cr, arena_reads);
+            }
+        }
+    }
+    // the whole batch's narrowed offsets, every segment with a closing entry of its own (a segment is closed when the next
+    // read does not fit: it is more than half full); run_slice looks at read lengths on the host when a range holds long reads
+    const uint64_t off_need = n + 2 + (one_segment ? 0 : 2 * (total_bases / arena_bases + n / arena_reads) + 8);
+    if (h_off_cap < off_need) {
+        if (h_off_all) (void)hipHostFree(h_off_all);
+        h_off_all = nullptr;
+        h_off_cap = off_need + n / 16;
+        HIP_CHECK(hipHostMalloc((void**)&h_off_all, h_off_cap * sizeof(uint32_t)));
+    }
+}
+
+void Batch::reserve_host(uint64_t n, uint64_t n_bases) {
+    HIP_CHECK(hipSetDevice(di->device));
+    host_room(n, n_bases, getenv("MTSV_TRACE") != nullptr);
+    if (!keep_on_device) {  // a result array of the size the first call will ask for, parked in the pool
+        uint64_t cap = 0;
+        mtsv_hit* h = pinned_hits_alloc(n + n / 8, &cap);
+        pinned_hits_release(h);
+    }
+}
+
+void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params& p, uint64_t read_base) {
+    const double t_entry = now_s();
+    HIP_CHECK(hipSetDevice(di->device));
+    std::vector<Batch*> ls{this};
+    for (auto& l : extra) ls.push_back(l.get());
+    const bool trace = getenv("MTSV_TRACE") != nullptr;
     // the parts as one batch: reads numbered through them, a virtual byte offset that ascends through them
     struct PartView {
         const uint8_t* bases;
@@ -874,37 +920,7 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
                        any_staged && any_direct ? " (some parts page-locked)" : "");
 
     // ---- arenas: segments of at most kArenaBases bases / kArenaReads reads (u32 offsets inside a segment) ----
-    uint64_t arena_bases = kArenaBases, arena_reads = kArenaReads;
-    if (const char* e = getenv("MTSV_ARENA_BASES")) arena_bases = std::max<uint64_t>(1 << 16, strtoull(e, nullptr, 10));  // (tests)
-    const bool one_segment = total_bases <= arena_bases && n <= arena_reads;
-    {
-        const uint64_t want_b = one_segment ? total_bases : arena_bases, want_r = one_segment ? n : std::min(n, arena_reads);
-        for (int k = 0; k < (one_segment ? 1 : 2); k++) {
-            Arena& ar = arena[k];
-            if (ar.cap_bases < want_b || ar.cap_reads < want_r) {
-                if (trace) fprintf(stderr, "[run_host] arena %d: %.1f MB of bases, %llu reads\n", k, want_b / 1e6, (unsigned long long)want_r);
-                (void)hipFree(ar.d_bases);
-                (void)hipFree(ar.d_off);
-                ar.d_bases = nullptr;
-                ar.d_off = nullptr;
-                ar.cap_bases = ar.cap_reads = 0;
-                const uint64_t cb = want_b + want_b / 16, cr = want_r + want_r / 16;  // a little room: the next batch is rarely the same size
-                dev_alloc(&ar.d_bases, std::min(cb, arena_bases) + 64, &bytes);  // k_search reads up to 36 bytes past a seed start
-                dev_alloc(&ar.d_off, std::min(cr, arena_reads) + 1, &bytes);
-                ar.cap_bases = std::min(cb, arena_bases);
-                ar.cap_reads = std::min(cr, arena_reads);
-            }
-        }
-    }
-    // the whole batch's narrowed offsets, every segment with a closing entry of its own (a segment is closed when the next
-    // read does not fit: it is more than half full); run_slice looks at read lengths on the host when a range holds long reads
-    const uint64_t off_need = n + 2 + (one_segment ? 0 : 2 * (total_bases / arena_bases + n / arena_reads) + 8);
-    if (h_off_cap < off_need) {
-        if (h_off_all) (void)hipHostFree(h_off_all);
-        h_off_all = nullptr;
-        h_off_cap = off_need + n / 16;
-        HIP_CHECK(hipHostMalloc((void**)&h_off_all, h_off_cap * sizeof(uint32_t)));
-    }
+    host_room(n, total_bases, trace);
     constexpr uint64_t kChunkMax = 32ull << 20, kChunkMin = 4ull << 20;
     if (!direct && !h_stage[0])
         for (auto& hs : h_stage) HIP_CHECK(hipHostMalloc((void**)&hs, kChunkMax + 64));

@@ -89,7 +89,9 @@ struct Batch {
     mtsv_batch_stats stats{};
     float stage_acc[MTSV_N_STAGES] = {0};
 
-    Batch(mtsv_index* ix, DeviceIndex* di, uint64_t max_reads, uint64_t max_bases, uint64_t hit_cap, Batch* parent = nullptr);
+    // lanes: ranges of a host batch that run through the kernels at once, each on a stream and workspace of its own (0: three,
+    // MTSV_LANES)
+    Batch(mtsv_index* ix, DeviceIndex* di, uint64_t max_reads, uint64_t max_bases, uint64_t hit_cap, Batch* parent = nullptr, int lanes = 0);
     ~Batch();
     Batch(const Batch&) = delete;
     Batch& operator=(const Batch&) = delete;
@@ -104,6 +106,9 @@ struct Batch {
         uint64_t n;
     };
     void run_host_parts(const HostPart* parts, int n_parts, const mtsv_params& p, uint64_t read_base = 0);
+    // everything run_host sizes by the batch it is given (device arenas, offset table, result array), for batches of up to
+    // n reads / n_bases bases, now
+    void reserve_host(uint64_t n, uint64_t n_bases);
     void download(mtsv_hit** hits, uint64_t* n);
     // the hits of the last run, still in HBM (keep_on_device was set), into caller memory that holds n == total_hits entries
     void download_into(mtsv_hit* dst, uint64_t n);
@@ -113,6 +118,7 @@ struct Batch {
     void begin_run(const mtsv_params& p);
     void reset_lane();
     void stage_reserve(uint64_t n_hits_needed);
+    void host_room(uint64_t n, uint64_t total_bases, bool trace);
     void finish_lane();
     void alloc_hit_workspace();
     void grow_hit_workspace(uint64_t need);

@@ -235,6 +235,39 @@ int mtsv_batch_create(mtsv_index* ix, int hip_device, uint64_t max_reads, uint64
     })
 }
 
+int mtsv_batch_create_lanes(mtsv_index* ix, int hip_device, uint64_t max_reads, uint64_t max_bases, uint64_t max_hits_ws, int lanes,
+                            mtsv_batch** out) {
+    if (!ix || !out || lanes < 0) return fail_arg("null argument");
+    GUARD({
+        std::lock_guard<std::mutex> lk(ix->mu);
+        *out = new mtsv_batch(ix, device_index(ix, hip_device), max_reads, max_bases, max_hits_ws, nullptr, lanes);
+    })
+}
+
+int mtsv_batch_reserve_host(mtsv_batch* b, uint64_t n_reads, uint64_t n_bases, uint32_t warm_read_len) {
+    if (!b) return fail_arg("null argument");
+    GUARD({
+        b->impl.reserve_host(n_reads, n_bases);
+        const std::vector<uint8_t>& text = b->impl.ix->host.text;
+        if (warm_read_len && text.size() >= (uint64_t)warm_read_len * 2 + 16) {
+            // reads sampled from the index through every kernel once: the first launch of a kernel loads its code object,
+            // the first pass of a lane sizes its seed arrays
+            const uint64_t n = std::min<uint64_t>(std::max<uint64_t>(n_reads, 1), std::max<uint64_t>(4096, (uint64_t)b->impl.n_lanes * 32768));
+            std::vector<uint8_t> bases(n * warm_read_len);
+            std::vector<uint64_t> off(n + 1);
+            if (mtsv_synth_reads(b->impl.ix, 0x7761726d, n, warm_read_len, bases.data(), off.data()) != MTSV_OK)
+                throw std::runtime_error(std::string("internal: ") + mtsv_last_error());
+            mtsv_params p;
+            mtsv_params_default(&p);
+            b->impl.run_host(bases.data(), off.data(), n, p);
+            mtsv_hit* h = nullptr;
+            uint64_t nh = 0;
+            b->impl.download(&h, &nh);
+            mtsv_hits_free(h);
+        }
+    })
+}
+
 int mtsv_batch_upload(mtsv_batch* b, const uint8_t* bases, const uint64_t* read_off, uint64_t n_reads) {
     if (!b || !read_off || (!bases && n_reads && read_off[n_reads] != read_off[0])) return fail_arg("null argument");
     GUARD(b->impl.upload(bases, read_off, n_reads))

@@ -1641,13 +1641,17 @@ __global__ __launch_bounds__(256) void k_resolve(uint32_t n_strands, int64_t max
                                                  const uint32_t* __restrict__ strand_ncand,
                                                  const uint32_t* __restrict__ cand_status, uint4* __restrict__ out,
                                                  uint32_t* __restrict__ strand_nout) {
-    uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
-    if (rs >= n_strands) return;
-    uint32_t nc = strand_ncand[rs];
+    const uint32_t rs = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool valid = rs < n_strands;
+    uint32_t nc = valid ? strand_ncand[rs] : 0;
     uint32_t nout = 0;
-    if (nc) {
-        uint32_t o = strand_off[rs];
-        if (max_candidates >= 0 && (uint64_t)nc > (uint64_t)max_candidates) nc = (uint32_t)max_candidates;  // index.rs:385-389
+    const uint32_t o = nc ? strand_off[rs] : 0;
+    if (max_candidates >= 0 && (uint64_t)nc > (uint64_t)max_candidates) nc = (uint32_t)max_candidates;  // index.rs:385-389
+    // a strand of many candidates (repeats: hundreds) is compacted by its whole wavefront, 64 candidates a step: one lane
+    // walking it alone was the tail of the kernel, ~0.1 ms in every pass however small
+    constexpr uint32_t kCoop = 32;
+    const bool big = nc > kCoop;
+    if (nc && !big) {
         for (uint32_t i = 0; i < nc; i++) {
             if (cand_status[o + i] == 2) {
                 if (nout != i) out[o + nout] = out[o + i];
@@ -1656,6 +1660,31 @@ __global__ __launch_bounds__(256) void k_resolve(uint32_t n_strands, int64_t max
             }
         }
     }
+    const uint32_t lane = lane_id();
+    // (the reference checks the cut-off after it has pushed a hit: at least one is kept)
+    const uint64_t cap = max_assignments < 0 ? ~0ull : (uint64_t)(max_assignments > 1 ? max_assignments : 1);
+    for (unsigned long long m = __ballot(big); m; m &= m - 1) {
+        const int l = __builtin_ctzll(m);
+        const uint32_t o_l = __builtin_amdgcn_readlane(o, l), nc_l = __builtin_amdgcn_readlane(nc, l);
+        uint32_t nout_l = 0;
+        for (uint32_t base = 0; base < nc_l; base += kWave) {
+            const uint32_t i = base + lane;
+            const bool pass = i < nc_l && cand_status[o_l + i] == 2;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (pass) v = out[o_l + i];
+            const unsigned long long pm = __ballot(pass);
+            const uint32_t pos = nout_l + (uint32_t)__popcll(pm & ((1ull << lane) - 1));
+            // (pos <= i, and every entry of this step has been read before one is written: the loads above complete first)
+            if (pass && (uint64_t)pos < cap) out[o_l + pos] = v;
+            nout_l += (uint32_t)__popcll(pm);
+            if ((uint64_t)nout_l >= cap) {  // index.rs:421-425
+                nout_l = (uint32_t)cap;
+                break;
+            }
+        }
+        if ((int)lane == l) nout = nout_l;
+    }
+    if (!valid) return;
     strand_nout[rs] = nout;
 }
 
@@ -1781,6 +1810,7 @@ void launch_edit_myers(hipStream_t s, const DevIndexView& ix, const EvalArgs& a_
     // max_items bounds the work list from far above (seed hits, not candidates); a grid of one resident generation at
     // most, and smaller when the list is short: workgroups cost ~0.1 us each to dispatch, with work or without, and
     // the lists are claimed 64 candidates at a time whatever the grid
+    // (4096, 1024 or 512 hits per workgroup: the same within the noise on passes of 84 k to 1 M reads)
     uint32_t blocks = std::max<uint32_t>(16, std::min<uint32_t>(cdiv(max_items, 4096), 256 * 5));
     uint32_t W = (max_len + 31) / 32;
 #define MYERS_CASE(WW)                                                                                   \

@@ -32,6 +32,8 @@ exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 
 
 def run(path, extra=(), env=None):
     e = dict(os.environ, **(env or {}))
+    if os.path.exists("/tmp/cli.out") and not os.environ.get("CLI_KEEP_OUT"):
+        os.remove("/tmp/cli.out")   # a fresh results file, as in a first run (closing a truncated 0.9 GB file costs ext4 70 ms)
     ru0 = resource.getrusage(resource.RUSAGE_CHILDREN)
     t0 = time.time()
     out = subprocess.run([exe, "--fastq", path, "-i", "/tmp/cli.idx", "-m", "/tmp/cli.out", "--force-overwrite", *extra],
@@ -55,14 +57,15 @@ if not os.environ.get("CLI_QUICK"):
     ref = run("/tmp/cli.fastq", env={"MTSV_SERIAL_INGEST": "1", "MTSV_HOST_THREADS": "1"})
     for env in ({"MTSV_HOST_THREADS": "4"}, {"MTSV_HOST_THREADS": "8"}, {"MTSV_HOST_THREADS": "16"}):
         assert run("/tmp/cli.fastq", env=env) == ref
-for br in ("65536", "131072", "262144", "524288"):
+for br in ("65536", "131072", "262144"):
     run("/tmp/cli.fastq", ["--batch-reads", br])
-run("/tmp/cli.fastq", ["--batch-reads", "131072"], env={"MTSV_CLI_GROUP_READS": "2097152"})
-run("/tmp/cli.fastq", ["--batch-reads", "65536"], env={"MTSV_CLI_GROUP_READS": "2097152"})
+for wk in ("1", "2", "3", "4"):
+    run("/tmp/cli.fastq", env={"MTSV_CLI_WORKERS": wk})
+run("/tmp/cli.fastq", env={"MTSV_CLI_COLD": "1"})       # workspaces not sized / warmed before the clock starts
+run("/tmp/cli.fastq", env={"MTSV_CLI_GROUP_READS": "2097152"})
 run("/tmp/cli.fastq")
 run("/tmp/cli.fastq", env={"MTSV_CLI_MARKS": "1"})   # the same with the time line of the run on stderr
 run("/tmp/cli.fastq", ["--batch-reads", "262144"], env={"MTSV_CLI_PAGEABLE": "1"})
 run("/tmp/cli.fastq", ["--devices", "0,0"])
-run("/tmp/cli.fastq", ["--devices", "0,0,0"])
 if do_gz:
     run("/tmp/cli.fastq.gz")
