@@ -16,6 +16,7 @@
 //                     file equals what mtsv-collapse makes of the per-chunk files (README.md:189,
 //                     collapse.rs:597-625: smallest edit per read and TaxId)
 #include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <atomic>
@@ -259,7 +260,22 @@ double parse_f64(const std::string& s, const char* what) {
 
 }  // namespace
 
+// MTSV_CLI_MARKS=1: the set-up phases on stderr as they end, in ms since the process began
+static void setup_mark(const char* what) {
+    static const bool on = getenv("MTSV_CLI_MARKS") != nullptr;
+    static struct timespec t0 = [] {
+        struct timespec t;
+        clock_gettime(CLOCK_MONOTONIC, &t);
+        return t;
+    }();
+    if (!on) return;
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    fprintf(stderr, "[cli set-up] %9.3f ms  %s\n", ((t.tv_sec - t0.tv_sec) + (t.tv_nsec - t0.tv_nsec) * 1e-9) * 1e3, what);
+}
+
 int main(int argc, char** argv) {
+    setup_mark("main");
     Args a;
     for (int i = 1; i < argc; i++) {
         std::string k = argv[i];
@@ -619,13 +635,13 @@ int main(int argc, char** argv) {
     // One library call takes every batch that is waiting, up to kGroupReads reads (mtsv_batch_run_host_parts): the device
     // is several times faster on passes of a million reads than on a quarter of that (a pass costs ~2.5 ms before it does
     // any work), while the parser is fastest on blocks of ~80 MB.
-    uint64_t kGroupReads = std::max<uint64_t>(a.batch_reads, 1ull << 20);
+    uint64_t kGroupReads = std::max<uint64_t>(a.batch_reads, 512ull << 10);
     if (const char* e = getenv("MTSV_CLI_GROUP_READS")) kGroupReads = std::max<uint64_t>(a.batch_reads, strtoull(e, nullptr, 10));
     const size_t group_max = (size_t)std::min<uint64_t>(32, std::max<uint64_t>(1, kGroupReads / std::max<uint64_t>(a.batch_reads, 1)));
     // Several workers per --devices entry, a workspace of ONE lane each: a call is copy in -> kernels -> hits out, and
     // what overlaps on the device are the calls of different workers (tools/call_stream.py: one worker with the
     // default three lanes 165 M reads/s on megaread calls, three workers of one lane 229 M).
-    size_t workers_per_device = 3;
+    size_t workers_per_device = 2;
     if (const char* e = getenv("MTSV_CLI_WORKERS")) workers_per_device = (size_t)std::max(1, std::min(8, atoi(e)));
     // (a small input is through before the extra workspaces have paid for themselves)
     uint64_t input_bytes = 0;
@@ -690,6 +706,7 @@ int main(int argc, char** argv) {
                 return 2;
             }
     }
+    setup_mark("index loaded and resident");
     // the workers' workspaces (one index): part of the device set-up, like making the index resident -- created, sized for
     // the calls to come and run once on reads sampled from the index (mtsv_batch_reserve_host)
     std::vector<mtsv_batch*> ws_ready(chunked ? 0 : n_workers, nullptr);
@@ -716,8 +733,10 @@ int main(int argc, char** argv) {
                 return 2;
             }
     }
+    setup_mark("workspaces ready");
     // parsed blocks land in page-locked memory from here on: the GPU copies them from where the parser put them
     if (stock_thread.joinable()) stock_thread.join();
+    setup_mark("stock of page-locked blocks ready");
     logmsg("INFO", "Beginning queries.");
     struct timespec w0;
     clock_gettime(CLOCK_MONOTONIC, &w0);
@@ -757,6 +776,7 @@ int main(int argc, char** argv) {
         std::deque<std::unique_ptr<Work>> q;
         bool closed = false;
         size_t cap = 2;
+        size_t n_takers = 1;  // threads that call pop_group
         void push(std::unique_ptr<Work> w) {
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return q.size() < cap || closed; });
@@ -777,6 +797,8 @@ int main(int argc, char** argv) {
                 if (q.empty() && closed) return {};
                 cv.wait_for(lk, std::chrono::microseconds(200));  // (idle() changes without a notification)
             }
+            // (the input has ended: what is left is shared out, so that the workers finish together)
+            if (closed && n_takers > 1) max_n = std::min(max_n, (q.size() + n_takers - 1) / n_takers);
             std::vector<std::unique_ptr<Work>> g;
             uint64_t r = 0;
             while (!q.empty() && g.size() < max_n && r < max_reads) {
@@ -812,6 +834,7 @@ int main(int argc, char** argv) {
     };
     Queue parsed, done;
     parsed.cap = (n_workers + 1) * group_max + 1;
+    parsed.n_takers = n_workers;
     done.cap = n_workers * group_max + 1;
     std::atomic<int> calls_in_flight{0};
     std::mutex err_mu;
@@ -1121,7 +1144,17 @@ int main(int argc, char** argv) {
                 t_fmt.load() * 1e-6, t_done_wait.load() * 1e-6, t_write_wait.load() * 1e-6);
     if (cli_timing && getenv("MTSV_CLI_MARKS"))
         for (auto& m : marks) fprintf(stderr, "[cli timing] %9.3f ms  %s\n", m.second * 1e3, m.first.c_str());
+    setup_mark("queries done");
+    // The results are on their way to the disk (close() has returned) and the log line is out: leave.  Handing 2 GB of
+    // page-locked blocks, the workspaces and the resident index back piece by piece takes 0.3 s that the kernel's own
+    // teardown of the process does not need (MTSV_CLI_CLEAN_EXIT=1: free everything, for leak checkers).
+    if (!getenv("MTSV_CLI_CLEAN_EXIT")) {
+        fflush(nullptr);  // (the reader thread may still be unmapping its input: it ends with the process)
+        _exit(0);
+    }
     for (auto* ws : ws_ready) mtsv_batch_free(ws);  // (30 ms per workspace: after the queries' clock, like the index)
+    setup_mark("workspaces freed");
     for (auto* ix : idx) mtsv_index_free(ix);
+    setup_mark("index freed");
     return 0;
 }

@@ -876,3 +876,35 @@ def test_run_host_parts_equals_one_batch(tricky, medium):
     assert_same_hits(b.download(), whole)
     b.close()
     hb.close()
+
+
+def test_one_lane_workspace_reserved_and_warmed_gives_the_same_hits(tricky, medium):
+    """mtsv_batch_create_lanes + mtsv_batch_reserve_host (what mtsv-binner's workers use): a workspace of one lane, sized
+    for its host batches and warmed on reads sampled from the index, returns the hits of the default workspace and of the
+    oracle; the warm-up leaves nothing behind in the next call's results or counters"""
+    ix, orc, reads = tricky
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want, octr = orc.bin_batch(bases, off, both_params()[1], threads=8)
+    b = M.Batch(ix, 0, 4096, 1 << 20, lanes=1)
+    b.reserve_host(len(reads), len(bases), warm_read_len=100)
+    b.run_host(bases, off)
+    assert_same_hits(b.download(), want)
+    st = b.stats()
+    assert st["n_lanes"] == 1 and st["n_reads"] == len(reads)
+    assert st["n_verified"] == octr["n_sw"] and st["n_candidates"] == octr["n_cand"] and st["n_seed_hits"] == octr["H"]
+    b.close()
+    mix, mbases, moff = medium
+    mix.to_device(0)
+    n = len(moff) - 1
+    whole = mix.bin_batch(mbases, moff, device=0)
+    for lanes in (1, 2):
+        b = M.Batch(mix, 0, n, n * 150, lanes=lanes)
+        b.reserve_host(n, len(mbases), warm_read_len=150)
+        b.reserve_host(n, len(mbases))           # a second time: nothing to do
+        b.run_host(mbases, moff)
+        assert_same_hits(b.download(), whole)
+        assert b.stats()["n_lanes"] <= lanes
+        b.close()
+    with pytest.raises(M.MtsvError):
+        M.Batch(mix, 0, n, n * 150, lanes=-1)

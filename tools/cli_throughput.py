@@ -59,10 +59,12 @@ if not os.environ.get("CLI_QUICK"):
         assert run("/tmp/cli.fastq", env=env) == ref
 for br in ("65536", "131072", "262144"):
     run("/tmp/cli.fastq", ["--batch-reads", br])
-for wk in ("1", "2", "3", "4"):
+for wk in ("1", "2", "3"):
     run("/tmp/cli.fastq", env={"MTSV_CLI_WORKERS": wk})
 run("/tmp/cli.fastq", env={"MTSV_CLI_COLD": "1"})       # workspaces not sized / warmed before the clock starts
-run("/tmp/cli.fastq", env={"MTSV_CLI_GROUP_READS": "2097152"})
+for gr in ("262144", "1048576"):
+    run("/tmp/cli.fastq", env={"MTSV_CLI_GROUP_READS": gr})
+    run("/tmp/cli.fastq", env={"MTSV_CLI_GROUP_READS": gr, "MTSV_CLI_WORKERS": "3"})
 run("/tmp/cli.fastq")
 run("/tmp/cli.fastq", env={"MTSV_CLI_MARKS": "1"})   # the same with the time line of the run on stderr
 run("/tmp/cli.fastq", ["--batch-reads", "262144"], env={"MTSV_CLI_PAGEABLE": "1"})
