@@ -203,7 +203,7 @@ template <int KK>
 __global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint8_t* __restrict__ bases,
                                                      const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t total,
                                                      uint32_t max_ns, uint32_t K, uint32_t G,
-                                                     uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt, uint64_t exp_mask) {
+                                                     uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
     __shared__ uint32_t slow_q[256];
     __shared__ uint32_t slow_n;
     if (threadIdx.x == 0) slow_n = 0;
@@ -274,7 +274,7 @@ __global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint
                 tix |= (uint64_t)(a & 3u) << 32;
                 i--;
             }
-            const uint2 iv = ix.kmer_tab[slow ? 0 : (tix & exp_mask)];
+            const uint2 iv = ix.kmer_tab[slow ? 0 : tix];
             lo = iv.x;
             hi = iv.y;
             for (; i >= 0; i--) {  // wave-uniform trip count
@@ -618,8 +618,7 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
     }
 #define FAST_CASE(KKV)                                                                                                  \
     hipLaunchKernelGGL((k_search_fast<KKV>), dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, (uint32_t)total, \
-                       max_ns, K, G, seed_lo, seed_cnt, exp_mask)
-    static const uint64_t exp_mask = getenv("MTSV_EXP_TIXMASK") ? strtoull(getenv("MTSV_EXP_TIXMASK"), nullptr, 0) : ~0ull;
+                       max_ns, K, G, seed_lo, seed_cnt)
     switch (ix.kmer_k) {
     case 12: FAST_CASE(12); break;
     case 13: FAST_CASE(13); break;
