@@ -474,7 +474,11 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         }
         // ---- seeds ----
         HIP_CHECK(hipEventRecord(ev[0], stream));
-        launch_search(stream, v, sb, so, (uint32_t)r0, nr, max_ns, K, G, d_seed_lo, d_seed_cnt);
+        // (d_seed_pre is k_thin's output: until then it holds the list of the slots that take the general code -- an N in
+        //  the seed's table part; counter slot 22.  The second kernel's grid covers the share of such slots the passes before
+        //  had, half as much again: the count is checked at the pass's first round trip below.)
+        const uint32_t listed_cap = (uint32_t)std::min<uint64_t>(slots, std::max<uint64_t>(4096, (uint64_t)((double)slots * listed_share)));
+        launch_search(stream, v, sb, so, (uint32_t)r0, nr, max_ns, K, G, d_seed_lo, d_seed_cnt, d_seed_pre, (uint32_t*)(d_counters + 22), listed_cap);
         HIP_CHECK(hipEventRecord(ev[1], stream));
         if (max_ns)
             launch_thin(stream, sb, so, (uint32_t)r0, nr, p.edit_rate, p.min_seed, max_ns, K, G, p.max_hits, p.tune_max_hits, d_seed_cnt,
@@ -485,8 +489,19 @@ void Batch::run_slice(const mtsv_params& p, const uint8_t* sb, const uint32_t* s
         }
         launch_scan(stream, d_strand_hits, nstr, d_tile_sums, d_counters + 0, d_strand_off);
         launch_publish(stream, d_counters, h_counters, 1);
+        launch_publish(stream, d_counters + 22, h_counters + 22, 1);
         HIP_CHECK(hipEventRecord(ev[2], stream));
         HIP_CHECK(hipStreamSynchronize(stream));
+        {
+            const uint64_t n_listed = h_counters[22] & 0xffffffffull;
+            const double share = slots ? (double)n_listed / (double)slots : 0.0;
+            if (n_listed > listed_cap) {  // more slots on the list than the grid covered: the pass again, with a grid for them
+                listed_share = std::min(1.0, share * 1.25 + 0.01);
+                if (getenv("MTSV_TRACE")) fprintf(stderr, "[lane] %llu listed seed slots, grid for %u: pass again\n", (unsigned long long)n_listed, listed_cap);
+                continue;
+            }
+            listed_share = std::min(1.0, std::max(0.02, share * 1.5 + 0.005));
+        }
         const uint64_t total_hits = h_counters[0];
         if (total_hits > hit_cap) {
             if (nr > 1) {

@@ -78,6 +78,7 @@ struct Batch {
     std::vector<uint32_t> h_read_off;
     uint32_t max_len = 0;
     static constexpr int kCounters = 24;
+    double listed_share = 0.125;  // seed slots that took the general search code in the last pass, with a margin (k_search_listed's grid)
     bool sw_diag = true;   // k_sw_pairs tries the ungapped diagonal as a lower bound first (MTSV_SW_DIAG=0: off)
     bool sw_top = true;      // ... and what they leave is swept on the top half of the read rows first (MTSV_SW_TOP=0: off)
     bool sw_bound = true;    // ... first by the edit-distance bound on the score (k_edit_myers in bound mode; MTSV_SW_BOUND=0: off)

@@ -194,21 +194,18 @@ __global__ __launch_bounds__(256) void k_search(DevIndexView ix, const uint8_t* 
 // steps, fewer than 2^32 slots -- without any data-dependent trip count: the table index comes straight from
 // the seed's code bytes (four codes of a dword squeezed to 8 bits; complementing is a bitwise NOT and the
 // reverse strand's byte order already is the table's), then exactly K - KK rank steps.  Seeds with an N in
-// the table part (about one in thirty; they walk up to K steps) are queued in LDS and run through the general
-// code afterwards, packed into the workgroup's first wavefront(s), so the long walks of a few lanes do not
-// hold every wavefront of the launch.  (A global list fed by one atomic per wavefront made the kernel
-// atomic-bound: ~9 ns per single-address atomic, 2.5 M wavefronts with such a seed on config2.)
+// the table part (about one in thirty; they walk up to K steps) are held back in LDS, per wavefront, and run through the
+// general code 64 at a time: the wavefronts stride over the slots (a grid of resident workgroups), so a wavefront
+// collects a full batch every ~1900 slots.  (One workgroup per 256 slots with its own queue walked ~9 such seeds on
+// one wavefront per workgroup -- a quarter of the kernel's time, measured by leaving them out; a global list fed by one
+// atomic per wavefront was atomic-bound: ~9 ns per single-address atomic, 2.5 M wavefronts with such a seed on config2.)
 // KK = 17: the 16 packed symbols plus the one in front of them as bits 32-33 of the table index (a table of 2^34 entries).
+// one seed slot on the table path: stores its interval, or returns true when the slot needs the general code (an N in the
+// table part)
 template <int KK>
-__global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint8_t* __restrict__ bases,
-                                                     const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t total,
-                                                     uint32_t max_ns, uint32_t K, uint32_t G,
-                                                     uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
-    __shared__ uint32_t slow_q[256];
-    __shared__ uint32_t slow_n;
-    if (threadIdx.x == 0) slow_n = 0;
-    __syncthreads();
-    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ inline bool fast_slot(const DevIndexView& ix, const uint8_t* __restrict__ bases, const uint32_t* __restrict__ read_off,
+                                 uint32_t r0, uint32_t total, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t slot,
+                                 uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt) {
     const bool in_range = slot < total;
     const uint32_t rs = in_range ? slot / max_ns : 0, j = in_range ? slot - rs * max_ns : 0;
     const uint32_t strand = rs & 1, r = r0 + (rs >> 1);
@@ -301,15 +298,73 @@ __global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint
         seed_lo[slot] = lo;
         seed_cnt[slot] = hi - lo;
     }
-    const unsigned long long sb = __ballot(slow);
-    if (sb) {
-        uint32_t base = 0;
-        if (lane_id() == 0) base = atomicAdd(&slow_n, (uint32_t)__popcll(sb));
-        base = __builtin_amdgcn_readfirstlane(base);
-        if (slow) slow_q[base + __popcll(sb & ((1ull << lane_id()) - 1))] = slot;
+    return slow;
+}
+
+constexpr uint32_t kSlowCap = 128;  // slots a wavefront holds back in LDS before it appends 64 of them to the list
+
+template <int KK>
+__global__ __launch_bounds__(256) void k_search_fast(DevIndexView ix, const uint8_t* __restrict__ bases,
+                                                     const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t total,
+                                                     uint32_t max_ns, uint32_t K, uint32_t G,
+                                                     uint32_t* __restrict__ seed_lo, uint32_t* __restrict__ seed_cnt,
+                                                     uint32_t* __restrict__ slow_list, uint32_t* __restrict__ slow_count) {
+    __shared__ uint32_t slow_all[256 / kWave][kSlowCap];
+    __shared__ uint32_t tail_q[256];
+    __shared__ uint32_t tail_n;
+    if (threadIdx.x == 0) tail_n = 0;
+    const uint32_t lane = lane_id(), wave = threadIdx.x / kWave;
+    uint32_t* slow_q = slow_all[wave];
+    uint32_t n_slow = 0;  // (wave-uniform)
+    const uint32_t n_tiles = (total + kWave - 1) / kWave;
+    for (uint32_t tile = blockIdx.x * (256 / kWave) + wave; tile < n_tiles; tile += gridDim.x * (256 / kWave)) {
+        const uint32_t slot = tile * kWave + lane;
+        const bool slow = fast_slot<KK>(ix, bases, read_off, r0, total, max_ns, K, G, slot, seed_lo, seed_cnt);
+        const unsigned long long sb = __ballot(slow);
+        if (sb) {
+            if (slow) slow_q[n_slow + __popcll(sb & ((1ull << lane) - 1))] = slot;
+            n_slow += (uint32_t)__popcll(sb);
+            if (n_slow >= kWave) {  // 64 of them leave for the list with one atomic
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                n_slow -= kWave;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(slow_count, kWave);
+                base = __builtin_amdgcn_readfirstlane(base);
+                slow_list[base + lane] = slow_q[n_slow + lane];
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
     }
+    // what the four wavefronts have left (fewer than 64 each) leaves with one atomic per workgroup
     __syncthreads();
-    if (threadIdx.x < slow_n) search_slot(ix, bases, read_off, r0, max_ns, K, G, slow_q[threadIdx.x], seed_lo, seed_cnt);
+    uint32_t at = 0;
+    if (lane == 0 && n_slow) at = atomicAdd(&tail_n, n_slow);
+    at = __builtin_amdgcn_readfirstlane(at);
+    if (lane < n_slow) tail_q[at + lane] = slow_q[lane];
+    __syncthreads();
+    const uint32_t nt = tail_n;
+    if (nt) {
+        __shared__ uint32_t tail_base;
+        if (threadIdx.x == 0) tail_base = atomicAdd(slow_count, nt);
+        __syncthreads();
+        if (threadIdx.x < nt) slow_list[tail_base + threadIdx.x] = tail_q[threadIdx.x];
+    }
+}
+
+// the listed slots through the general code, every lane of a wavefront busy.  One entry per thread, no loop (a grid that
+// strides over the device-side count keeps every field of the index view live across the loop: scalar-register spills):
+// the host sizes the grid from the share of such slots in the passes before (batch.hip: it runs the pass again when the
+// list turned out longer than the grid).
+__global__ __launch_bounds__(256) void k_search_listed(DevIndexView ix, const uint8_t* __restrict__ bases,
+                                                       const uint32_t* __restrict__ read_off, uint32_t r0, uint32_t max_ns, uint32_t K,
+                                                       uint32_t G, const uint32_t* __restrict__ slow_list,
+                                                       const uint32_t* __restrict__ slow_count, uint32_t* __restrict__ seed_lo,
+                                                       uint32_t* __restrict__ seed_cnt) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= *slow_count) return;
+    search_slot(ix, bases, read_off, r0, max_ns, K, G, slow_list[i], seed_lo, seed_cnt);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -606,7 +661,9 @@ void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t 
 }
 
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
-                   uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt) {
+                   uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt,
+                   uint32_t* slow_list, uint32_t* slow_count, uint32_t listed_cap) {
+    (void)hipMemsetAsync(slow_count, 0, sizeof(uint32_t), s);  // (whichever path is taken: the caller reads it after every pass)
     uint64_t total = (uint64_t)n_reads * 2 * max_ns;
     if (!total) return;
     const bool fast = ix.kmer_tab && total < 0xffffffffull && K >= 16 && K <= 24 && ix.kmer_k >= 12 && ix.kmer_k <= 17 &&
@@ -616,9 +673,12 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
                            seed_lo, seed_cnt);
         return;
     }
+    // resident wavefronts that stride over the slots (a wavefront fills a batch of 64 held-back slots every ~1900)
+    // (two generations of resident workgroups: 0.81 ms per pass of 1 Mi reads, 0.84 with one, 0.82 with half of one)
+    const dim3 grid(std::min<uint32_t>(cdiv(total, 256), 256 * 16));
 #define FAST_CASE(KKV)                                                                                                  \
-    hipLaunchKernelGGL((k_search_fast<KKV>), dim3(cdiv(total, 256)), dim3(256), 0, s, ix, bases, read_off, r0, (uint32_t)total, \
-                       max_ns, K, G, seed_lo, seed_cnt)
+    hipLaunchKernelGGL((k_search_fast<KKV>), grid, dim3(256), 0, s, ix, bases, read_off, r0, (uint32_t)total, max_ns, K, G, seed_lo, \
+                       seed_cnt, slow_list, slow_count)
     switch (ix.kmer_k) {
     case 12: FAST_CASE(12); break;
     case 13: FAST_CASE(13); break;
@@ -628,6 +688,9 @@ void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, 
     default: FAST_CASE(16); break;
     }
 #undef FAST_CASE
+    // (about one slot in thirty with the synthetic reads' 0.2 % of N)
+    hipLaunchKernelGGL(k_search_listed, dim3(cdiv(std::max<uint32_t>(listed_cap, 1), 256)), dim3(256), 0, s, ix, bases, read_off, r0, max_ns, K, G,
+                       slow_list, slow_count, seed_lo, seed_cnt);
 }
 
 void launch_thin(hipStream_t s, const uint8_t* bases, const uint32_t* read_off, uint32_t r0, uint32_t n_reads, double edit_rate,

@@ -88,7 +88,10 @@ void launch_publish(hipStream_t s, const uint64_t* src, uint64_t* dst_host, uint
 // base normalisation of bytes [begin, end) of a read buffer, src -> dst (may be equal): every other kernel expects codes
 void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end);
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
-                   uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt);
+                   uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt,
+                   uint32_t* slow_list, uint32_t* slow_count, uint32_t listed_cap);
+// slow_list: room for every seed slot; *slow_count: a counter of the lane; listed_cap: list entries the second kernel's grid covers
+// (the caller compares *slow_count with it afterwards)
 // strand_nseeds receives one word per strand for the coalescing kernels: min_seeds (index.rs:358) | edit tolerance << 16 |
 // a flag for the strands no candidate of which can be accepted (more N in the read than the edit tolerance, or the usize
 // wrap of index.rs:406)

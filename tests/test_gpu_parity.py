@@ -908,3 +908,30 @@ def test_one_lane_workspace_reserved_and_warmed_gives_the_same_hits(tricky, medi
         b.close()
     with pytest.raises(M.MtsvError):
         M.Batch(mix, 0, n, n * 150, lanes=-1)
+
+
+def test_batches_rich_in_n_overflow_the_listed_search_grid_and_run_again(small_db):
+    """seeds with an N in their table part go to a list that a second kernel walks; its grid is sized from the share of
+    such seeds in the passes before (an eighth at first), and a pass whose list is longer runs again.  Reads with an N
+    every dozen bases (three seeds in four on the list), then clean reads, then N-rich ones again -- on one workspace, so
+    that the share is learnt, unlearnt and exceeded again -- against the oracle"""
+    ix, orc = small_db
+    ix.to_device(0)
+    rng = np.random.default_rng(3)
+    clean, off = M.synth_reads(ix, seed=77, n_reads=6000, read_len=150)
+    dirty = clean.copy()
+    dirty[rng.random(len(dirty)) < 0.08] = ord("N")
+    mp, op = both_params(edit_rate=0.2)     # (tolerant enough for some N-rich reads to be assigned)
+    want_dirty, ctr = orc.bin_batch(dirty, off, op, threads=8)
+    want_clean, _ = orc.bin_batch(clean, off, op, threads=8)
+    assert len(want_dirty) > 100 and len(want_clean) > 4000
+    b = M.Batch(ix, 0, 6000, len(clean))
+    for bases, want in ((dirty, want_dirty), (clean, want_clean), (clean, want_clean), (dirty, want_dirty)):
+        b.upload(bases, off)
+        b.run(mp)
+        assert_same_hits(b.download(), want)
+    st = b.stats()
+    assert st["n_seed_hits"] == ctr["H"] and st["n_candidates"] == ctr["n_cand"]   # the repeated pass is counted once
+    b.run_host(dirty, off, mp)
+    assert_same_hits(b.download(), want_dirty)
+    b.close()
