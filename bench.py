@@ -629,7 +629,7 @@ def main():
     K_seed = params.seed_size
     kk = info.get("kmer_k", 0)
     W_words = (read_len + 31) // 32
-    kernels_ms = {"k_search": stage_ms["search"], "k_thin + scan": stage_ms["thin_scan"], "k_expand / k_locate": stage_ms["expand"] + stage_ms["locate"],
+    kernels_ms = {"k_search_fast + k_search_listed": stage_ms["search"], "k_thin + scan": stage_ms["thin_scan"], "k_expand / k_locate": stage_ms["expand"] + stage_ms["locate"],
                   "k_coalesce (+ _mid, _heavy)": stage_ms["coalesce"], "k_sw_diag": st1.get("sw_diag_ms", 0.0),
                   "k_edit_myers (prefilter bound)": st1.get("sw_bound_ms", 0.0), "k_sw_pairs": st1.get("sw_sweep_ms", 0.0),
                   "k_edit_myers (edit distance)": st1.get("edit_ms", 0.0), "scan + k_gather": stage_ms["gather"]}
@@ -645,7 +645,7 @@ def main():
     search_ms = stage_ms["search"]
     seeds = st1["n_seed_slots"]
     alg_search = seeds * (8 + 2 * 64 * max(0, K_seed - kk) + K_seed) if kk else None
-    roof = {"bound": "hbm", "kernel": f"k_search_fast<{kk}> (FMIndex::backward_search, index.rs:305)" if kk else "k_search",
+    roof = {"bound": "hbm", "kernel": f"k_search_fast<{kk}> + k_search_listed, the search stage (FMIndex::backward_search, index.rs:305)" if kk else "k_search",
             "kernel_ms": search_ms, "share_of_resident_step": search_ms / stage_ms["total"] if stage_ms.get("total") else None,
             "achieved": None, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": None, "traffic": None,
             "kernels_ms": kernels_ms}
