@@ -253,14 +253,22 @@ def test_parallel_ingest_and_formatting_equal_the_serial_pipeline(tmp_path):
             s = bases[off[i]:off[i + 1]].tobytes()
             f.write(b"@q%d extra words\n%s\n+\n%s\n" % (i, s, b"I" * len(s)))
     outs = {}
-    for name, env in (("serial", {"MTSV_SERIAL_INGEST": "1", "MTSV_HOST_THREADS": "1"}),
-                      ("par", {"MTSV_HOST_THREADS": "6", "MTSV_INGEST_BLOCK": str(1 << 20)})):
+    # "workers": what a large input gets by default -- several workers with a one-lane workspace each, sized and warmed
+    # before the queries (mtsv_batch_create_lanes / _reserve_host), taking groups of batches (here four of 10 000 reads);
+    # "clean": the same with the orderly teardown instead of _exit
+    many = {"MTSV_CLI_WORKERS": "3", "MTSV_CLI_GROUP_READS": "40000", "MTSV_HOST_THREADS": "6", "MTSV_INGEST_BLOCK": str(1 << 20)}
+    for name, env, batch in (("serial", {"MTSV_SERIAL_INGEST": "1", "MTSV_HOST_THREADS": "1"}, "70000"),
+                             ("par", {"MTSV_HOST_THREADS": "6", "MTSV_INGEST_BLOCK": str(1 << 20)}, "70000"),
+                             ("workers", many, "10000"),
+                             ("clean", dict(many, MTSV_CLI_CLEAN_EXIT="1", MTSV_CLI_TIMING="1", MTSV_CLI_MARKS="1"), "10000")):
         out = tmp_path / f"{name}.txt"
-        r = subprocess.run([BIN, "--fastq", str(fq), "-i", str(idx), "-m", str(out), "--force-overwrite", "--batch-reads", "70000"],
+        r = subprocess.run([BIN, "--fastq", str(fq), "-i", str(idx), "-m", str(out), "--force-overwrite", "--batch-reads", batch],
                            capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
         assert r.returncode == 0, r.stdout + r.stderr
+        assert "threads terminated" in r.stdout
         outs[name] = open(out, "rb").read()
     assert outs["par"] == outs["serial"]
+    assert outs["workers"] == outs["serial"] and outs["clean"] == outs["serial"]
     orc = O.Index.read(str(idx))
     hits, _ = orc.bin_batch(bases, off, O.default_params(), threads=8)
     want = set()
