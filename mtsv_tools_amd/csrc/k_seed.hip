@@ -408,35 +408,45 @@ __global__ __launch_bounds__(256) void k_thin(const uint8_t* __restrict__ bases,
         nseeds++;
     }
     {
-        // the two strands of a read sit in neighbouring lanes (rs even / odd): the even lane counts the read's N once
-        // for both, and only when one of them has seed hits (only such strands can have candidates)
+        // the two strands of a read sit in neighbouring lanes (rs even / odd): the pair counts the read's N once, half of
+        // the read each, and only when one of the strands has seed hits (only such strands can have candidates)
         const bool need = total != 0;
         const int other_need = __shfl_xor((int)need, 1);  // (unconditionally: both lanes of the pair take part in the exchange)
         const bool pair_need = need || other_need != 0;
         const uint32_t ED = (uint32_t)ceil((double)L * edit_rate);  // index.rs:281-282
         bool hopeless = 2ull * ED > (uint64_t)L;
         uint32_t nn = 0;
-        if (pair_need && !hopeless && !(rs & 1)) {
-            // codes are 0..4, N = 4: bit 2 of every byte; aligned 16-byte groups of the code buffer (padded past its end)
+        if (pair_need && !hopeless) {
+            // codes are 0..4, N = 4: bit 2 of every byte; aligned 16-byte groups of the code buffer (padded past its end).
+            // The two lanes of the pair share the read's groups (even lane: even groups), and only the first and the last
+            // group hold bytes of the neighbouring reads.
             const uint4* b128 = reinterpret_cast<const uint4*>(bases);
-            const uint32_t q0 = b0 >> 4, q1 = (b0 + L + 15) >> 4;
-            for (uint32_t qi = q0; qi < q1; qi++) {
+            const uint32_t q0 = b0 >> 4, q1 = (b0 + L + 15) >> 4;  // groups [q0, q1)
+            auto masked = [&](uint32_t qi) {
                 const uint4 v = b128[qi];
-                uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+                uint32_t cnt = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const uint32_t byte0 = qi * 16 + 4 * k;  // buffer position of this dword's first byte
                     uint32_t m = (w[k] >> 2) & 0x01010101u;
-                    // bytes outside [b0, b0 + L) belong to the neighbouring reads
                     const int lo = (int)b0 - (int)byte0, hi = (int)(b0 + L) - (int)byte0;  // valid bytes [lo, hi) of this dword
                     if (lo > 0) m = lo >= 4 ? 0u : (m & (0xffffffffu << (8 * lo)));
                     if (hi < 4) m = hi <= 0 ? 0u : (m & ((1u << (8 * hi)) - 1u));
-                    nn += __popc(m);
+                    cnt += __popc(m);
                 }
+                return cnt;
+            };
+            const uint32_t half = rs & 1, ng = q1 - q0;  // group g of the read goes to the lane with (g & 1) == half
+            if (ng >= 1 && half == 0) nn += masked(q0);
+            if (ng >= 2 && half == ((ng - 1) & 1)) nn += masked(q1 - 1);
+            for (uint32_t g = half ? 1 : 2; g + 1 < ng; g += 2) {  // the groups between the two: all bytes are the read's
+                const uint4 v = b128[q0 + g];
+                nn += __popc((v.x >> 2) & 0x01010101u) + __popc((v.y >> 2) & 0x01010101u) + __popc((v.z >> 2) & 0x01010101u) +
+                      __popc((v.w >> 2) & 0x01010101u);
             }
         }
-        const uint32_t from_even = (uint32_t)__shfl_xor((int)nn, 1);  // every lane takes part in the exchange
-        if (rs & 1) nn = from_even;                                     // odd lane: its read's count from the even lane
+        nn += (uint32_t)__shfl_xor((int)nn, 1);  // the pair's two halves (every lane takes part in the exchange)
         hopeless = hopeless || nn > ED;
         // what the coalescing kernels need of this strand, in one word: min_seeds = max(1, floor(n_seeds * pct))
         // (index.rs:358; saturated at 16 bits, above any candidate's seed count), the edit tolerance, the flag
