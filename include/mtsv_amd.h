@@ -240,6 +240,14 @@ int mtsv_format_results(const mtsv_hit *hits, uint64_t n_hits, const char *ids,
                         uint64_t *out_len);
 void mtsv_free(void *p);
 
+/* ---- the transfer format of mtsv_batch_run_host*, exposed for tests (not part of the drop-in) ---- */
+/* The bases of a host batch cross PCIe as 4-bit codes, two per byte (src/binner.rs:88-100 applied on the host: A/a C/c
+ * G/g T/t -> 0..3, any other byte -> 4): src[0, n) are the bases at offsets [first_offset, first_offset + n) of a segment,
+ * dst receives bytes [first_offset / 2, (first_offset + n + 1) / 2) of its packed image (base i in nibble i & 1 of byte
+ * i / 2); prev_code is the code of the base before the first (it shares the first byte when first_offset is odd).
+ * Returns the code of the last base. */
+uint8_t mtsv_pack_bases(uint8_t *dst, const uint8_t *src, uint64_t first_offset, uint64_t n, uint8_t prev_code);
+
 /* ---- synthetic workloads for bench.py / tests (not part of the drop-in) ---- */
 /* i.i.d. ACGT reference of n_taxa x gis_per_taxon sequences of seq_len, 5% of each overwritten by
  * a 1%-diverged copy from another taxon, 0.1% of positions in N runs; built straight into an index */

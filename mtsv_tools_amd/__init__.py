@@ -23,6 +23,7 @@ from ._lib import (  # noqa: F401
     format_results,
     lib,
     lib_path,
+    pack_bases,
     set_build_device,
     synth_reads,
     version,

@@ -66,7 +66,7 @@ EXPORTS = [
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads", "mtsv_bin_batch_workspace_reads",
     "mtsv_bin_batch_multi", "mtsv_bin_batch_chunks", "mtsv_set_default_verify_mode",
     "mtsv_host_alloc", "mtsv_host_free", "mtsv_host_register", "mtsv_host_unregister",
-    "mtsv_batch_create_lanes", "mtsv_batch_reserve_host",
+    "mtsv_batch_create_lanes", "mtsv_batch_reserve_host", "mtsv_pack_bases",
 ]
 
 _lib = None
@@ -104,6 +104,8 @@ def lib():
         L.mtsv_batch_create.argtypes = [vp, i32, u64, u64, u64, C.POINTER(vp)]
         L.mtsv_batch_create_lanes.argtypes = [vp, i32, u64, u64, u64, i32, C.POINTER(vp)]
         L.mtsv_batch_reserve_host.argtypes = [vp, u64, u64, u32]
+        L.mtsv_pack_bases.argtypes = [vp, vp, u64, u64, C.c_uint8]
+        L.mtsv_pack_bases.restype = C.c_uint8
         L.mtsv_batch_upload.argtypes = [vp, vp, vp, u64]
         L.mtsv_batch_run.argtypes = [vp, C.POINTER(Params)]
         L.mtsv_batch_run_host.argtypes = [vp, vp, vp, u64, C.POINTER(Params)]
@@ -181,6 +183,16 @@ class HostBuffer:
             self.array = None
             lib().mtsv_host_free(self.ptr)
             self.ptr = None
+
+
+def pack_bases(bases, first_offset=0, prev_code=0):
+    """mtsv_pack_bases: the transfer format of run_host (4-bit codes, two per byte) of a uint8 array of bases that starts
+    at segment offset first_offset; returns (packed bytes, code of the last base)"""
+    bases = np.ascontiguousarray(bases, dtype=np.uint8)
+    n = len(bases)
+    out = np.zeros(((first_offset + n + 1) >> 1) - (first_offset >> 1) + 1, dtype=np.uint8)
+    last = lib().mtsv_pack_bases(out.ctypes.data, bases.ctypes.data, first_offset, n, prev_code)
+    return out[:-1], last
 
 
 def host_register(arr):

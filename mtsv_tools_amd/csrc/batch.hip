@@ -173,6 +173,7 @@ Batch::~Batch() {
     }
     for (auto& ar : arena) {
         (void)hipFree(ar.d_bases);
+        (void)hipFree(ar.d_packed);
         (void)hipFree(ar.d_off);
     }
     if (h_off_all) (void)hipHostFree(h_off_all);
@@ -857,12 +858,15 @@ void Batch::host_room(uint64_t n, uint64_t total_bases, bool trace) {
             if (ar.cap_bases < want_b || ar.cap_reads < want_r) {
                 if (trace) fprintf(stderr, "[run_host] arena %d: %.1f MB of bases, %llu reads\n", k, want_b / 1e6, (unsigned long long)want_r);
                 (void)hipFree(ar.d_bases);
+                (void)hipFree(ar.d_packed);
                 (void)hipFree(ar.d_off);
                 ar.d_bases = nullptr;
+                ar.d_packed = nullptr;
                 ar.d_off = nullptr;
                 ar.cap_bases = ar.cap_reads = 0;
                 const uint64_t cb = want_b + want_b / 16, cr = want_r + want_r / 16;  // a little room: the next batch is rarely the same size
                 dev_alloc(&ar.d_bases, std::min(cb, arena_bases) + 64, &bytes);  // k_search reads up to 36 bytes past a seed start
+                dev_alloc(&ar.d_packed, std::min(cb, arena_bases) / 2 + 64, &bytes);
                 dev_alloc(&ar.d_off, std::min(cr, arena_reads) + 1, &bytes);
                 ar.cap_bases = std::min(cb, arena_bases);
                 ar.cap_reads = std::min(cr, arena_reads);
@@ -937,7 +941,11 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
     // ---- arenas: segments of at most kArenaBases bases / kArenaReads reads (u32 offsets inside a segment) ----
     host_room(n, total_bases, trace);
     constexpr uint64_t kChunkMax = 32ull << 20, kChunkMin = 4ull << 20;
-    if (!direct && !h_stage[0])
+    // The bases cross PCIe as 4-bit codes, packed on the host chunk by chunk into page-locked staging buffers while the
+    // chunk before is on its way -- when the process has the CPUs for it (host_pack.hpp).  Otherwise, and with
+    // MTSV_H2D_PLAIN=1: the bytes as they are (from page-locked memory in place) and k_normalise on the device.
+    const bool packed = !getenv("MTSV_H2D_PLAIN") && pack_threads() >= kPackWorthwhile;
+    if ((packed || !direct) && !h_stage[0])
         for (auto& hs : h_stage) HIP_CHECK(hipHostMalloc((void**)&hs, kChunkMax + 64));
 
     struct Chunk {
@@ -1041,6 +1049,7 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
             uint64_t r = 0, seg = 0, seg_first_base = first_base, seg_first_read = 0;
             uint64_t chunk_bytes = kChunkMin;
             size_t k = 0;
+            uint8_t prev_code = 0;  // packed transfer: the code of the segment's last base so far (it may share a byte with the next)
             while (r < n) {
                 // the chunk: whole reads, about chunk_bytes of bases, inside the current segment
                 uint64_t e = r;
@@ -1108,7 +1117,7 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
                 hipEvent_t ev = event_for(k);
                 if (nb) {
                     const uint8_t* src = src_part.bases + poff[0];
-                    if (!src_part.pinned) {
+                    if (packed || !src_part.pinned) {
                         uint8_t* hs = h_stage[k % kStage];
                         if (k >= kStage) {  // its last copy must have left (polled, like the watcher)
                             for (;;) {
@@ -1118,10 +1127,18 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
                                 std::this_thread::sleep_for(std::chrono::microseconds(20));
                             }
                         }
-                        parallel_copy(hs, src, nb);
+                        if (packed) {
+                            if (dst_b == 0) prev_code = 0;  // a new segment
+                            prev_code = pack_chunk(hs, src, dst_b, nb, prev_code);
+                        } else {
+                            parallel_copy(hs, src, nb);
+                        }
                         src = hs;
                     }
-                    HIP_CHECK(hipMemcpyAsync(ar->d_bases + dst_b, src, nb, hipMemcpyHostToDevice, copy_stream));
+                    if (packed)
+                        HIP_CHECK(hipMemcpyAsync(ar->d_packed + (dst_b >> 1), src, ((dst_b + nb + 1) >> 1) - (dst_b >> 1), hipMemcpyHostToDevice, copy_stream));
+                    else
+                        HIP_CHECK(hipMemcpyAsync(ar->d_bases + dst_b, src, nb, hipMemcpyHostToDevice, copy_stream));
                 }
                 HIP_CHECK(hipMemcpyAsync(ar->d_off + dst_r, ho, (cnt + 1) * 4, hipMemcpyHostToDevice, copy_stream));
                 HIP_CHECK(hipEventRecord(ev, copy_stream));
@@ -1229,7 +1246,8 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
                 const double t0 = now_s();
                 // base normalisation (binner.rs:88-100) in place, on the lane's own stream: a kernel on the copy
                 // stream would queue behind the persistent verification kernels of the other lanes
-                launch_normalise(lane->stream, ar.d_bases, ar.d_bases, ho[0], ho[re - rb]);
+                if (packed) launch_unpack(lane->stream, ar.d_packed, ar.d_bases, ho[0], ho[re - rb]);
+                else launch_normalise(lane->stream, ar.d_bases, ar.d_bases, ho[0], ho[re - rb]);
                 lane->run_slice(p, ar.d_bases, dso, ho, re - rb, ml, read_base + rb);
                 if (trace) fprintf(stderr, "[run_host] range %llu (reads %llu..%llu): kernels %.1f ms, done at %.1f ms\n", (unsigned long long)k, (unsigned long long)rb, (unsigned long long)re, (now_s() - t0) * 1e3, (now_s() - run_t0) * 1e3);
                 {

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "../../include/mtsv_amd.h"
+#include "host_pack.hpp"
 #include "dev_index.hpp"
 #include "kernels.hpp"
 
@@ -21,6 +22,7 @@ struct Batch {
     // feeder thread on copy_stream; page-locked staging chunks for bases that lie in ordinary memory
     struct Arena {
         uint8_t* d_bases = nullptr;
+        uint8_t* d_packed = nullptr;  // the same bases as they arrive: 4-bit codes, two per byte (host_pack.hpp)
         uint32_t* d_off = nullptr;
         uint64_t cap_bases = 0, cap_reads = 0;
     };

@@ -688,6 +688,10 @@ int main(int argc, char** argv) {
         const uint64_t stock_bytes = std::min<uint64_t>(est / 2 + (1 << 20), 512ull << 20);
         stock_thread = std::thread([&pool, n_stock, stock_bytes] { pool.stock(n_stock, stock_bytes); });
     }
+    // The library would pack the bases to 4-bit codes on the host before they cross PCIe (host_pack.hpp: a dozen threads);
+    // here the parser's threads need the CPUs and the link is not what bounds a run: the blocks go as they are
+    // (MTSV_CLI_PACKED=1: packed).
+    if (!getenv("MTSV_CLI_PACKED")) setenv("MTSV_H2D_PLAIN", "1", 0);
     // the two acceptance predicates are evaluated edit distance first (identical hits, about twice the device
     // rate for reads up to 253 bases); MTSV_VERIFY=reference keeps the reference's order
     if (!getenv("MTSV_VERIFY")) mtsv_set_default_verify_mode(MTSV_VERIFY_EDIT_FIRST);

@@ -678,6 +678,10 @@ int mtsv_synth_index(uint64_t seed, uint32_t n_taxa, uint32_t gis_per_taxon, uin
     })
 }
 
+uint8_t mtsv_pack_bases(uint8_t* dst, const uint8_t* src, uint64_t first_offset, uint64_t n, uint8_t prev_code) {
+    return mtsv::pack_chunk(dst, src, first_offset, n, prev_code);
+}
+
 int mtsv_synth_reads(const mtsv_index* ix, uint64_t seed, uint64_t n_reads, uint32_t read_len, uint8_t* bases,
                      uint64_t* read_off) {
     if (!ix || !bases || !read_off || read_len == 0) return fail_arg("null argument");

@@ -34,6 +34,28 @@ __global__ __launch_bounds__(256) void k_normalise(const uint8_t* src, uint8_t* 
     *reinterpret_cast<uint4*>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
+// the same for reads that came over PCIe as 4-bit codes (host_pack.cpp): base i of the segment is nibble (i & 1) of
+// packed[i / 2]; bytes [lo, hi) of dst are written, sixteen per thread, the edge groups byte by byte as above
+__global__ __launch_bounds__(256) void k_unpack(const uint8_t* __restrict__ packed, uint8_t* __restrict__ dst, uint64_t lo, uint64_t hi) {
+    const uint64_t i = (lo & ~15ull) + ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) * 16;
+    if (i >= hi) return;
+    if (i < lo || i + 16 > hi) {
+        const uint64_t a = i < lo ? lo : i, b = i + 16 > hi ? hi : i + 16;
+        for (uint64_t q = a; q < b; q++) dst[q] = (uint8_t)((packed[q >> 1] >> (4 * (q & 1))) & 0xfu);
+        return;
+    }
+    const uint2 v = *reinterpret_cast<const uint2*>(packed + (i >> 1));  // (i is a multiple of 16: 8-byte aligned)
+    const uint32_t in[2] = {v.x, v.y};
+    uint32_t w[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t h = (in[k >> 1] >> (16 * (k & 1))) & 0xffffu;  // four nibbles
+        const uint32_t t = (h | (h << 8)) & 0x00ff00ffu;              // bytes 0 and 2: two nibbles each
+        w[k] = (t | (t << 4)) & 0x0f0f0f0fu;
+    }
+    *reinterpret_cast<uint4*>(dst + i) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
 // K1: backward search, one lane per seed slot
 // ---------------------------------------------------------------------------------------------
@@ -668,6 +690,11 @@ void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t 
     if (end <= begin) return;
     const uint64_t n = end - (begin & ~15ull);  // 16-byte groups, the first one aligned
     hipLaunchKernelGGL(k_normalise, dim3(cdiv((n + 15) / 16, 256)), dim3(256), 0, s, src, dst, begin, end);
+}
+void launch_unpack(hipStream_t s, const uint8_t* packed, uint8_t* dst, uint64_t lo, uint64_t hi) {
+    if (hi <= lo) return;
+    const uint64_t groups = ((hi + 15) >> 4) - (lo >> 4);
+    hipLaunchKernelGGL(k_unpack, dim3((uint32_t)cdiv(groups, 256)), dim3(256), 0, s, packed, dst, lo, hi);
 }
 
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,

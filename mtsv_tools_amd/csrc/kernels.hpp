@@ -87,6 +87,8 @@ constexpr uint32_t kMaxReadLen = 32767;        // the tiled kernel's packed 16-b
 void launch_publish(hipStream_t s, const uint64_t* src, uint64_t* dst_host, uint32_t n);
 // base normalisation of bytes [begin, end) of a read buffer, src -> dst (may be equal): every other kernel expects codes
 void launch_normalise(hipStream_t s, const uint8_t* src, uint8_t* dst, uint64_t begin, uint64_t end);
+// run_host's transfer format (4-bit codes, host_pack.hpp) into byte codes: bytes [lo, hi) of dst from packed[lo / 2 ...]
+void launch_unpack(hipStream_t s, const uint8_t* packed, uint8_t* dst, uint64_t lo, uint64_t hi);
 void launch_search(hipStream_t s, const DevIndexView& ix, const uint8_t* bases, const uint32_t* read_off, uint32_t r0,
                    uint32_t n_reads, uint32_t max_ns, uint32_t K, uint32_t G, uint32_t* seed_lo, uint32_t* seed_cnt,
                    uint32_t* slow_list, uint32_t* slow_count, uint32_t listed_cap);

@@ -151,3 +151,45 @@ def test_synthetic_workload_is_deterministic():
     rb, ob = M.synth_reads(b, 9, 500, 100)
     assert np.array_equal(ra, rb) and np.array_equal(oa, ob)
     assert a.info()["n"] == 4 * 2 * 3000 + 1
+
+
+def test_pack_bases_is_the_normalisation_of_the_reference_in_four_bits():
+    """mtsv_pack_bases (the transfer format of mtsv_batch_run_host*): every byte value, every alignment of a chunk inside
+    its segment, chunks chained through the shared byte, lengths on both sides of the vector and thread thresholds --
+    against binner.rs:88-100 written out in numpy (A/a C/c G/g T/t -> 0..3, anything else -> 4)"""
+    import numpy as np
+    import mtsv_tools_amd as M
+
+    lut = np.full(256, 4, dtype=np.uint8)
+    for k, ch in enumerate("ACGT"):
+        lut[ord(ch)] = lut[ord(ch.lower())] = k
+    rng = np.random.default_rng(11)
+
+    def image(codes, first):   # bytes [first / 2, (first + n + 1) / 2) of the segment's packed image
+        seg = np.zeros(first + len(codes) + 2, dtype=np.uint8)
+        seg[first:first + len(codes)] = codes
+        b = seg[0::2][: (len(seg) + 1) // 2].copy()
+        hi = seg[1::2]
+        b[: len(hi)] |= hi << 4
+        return b[first >> 1:(first + len(codes) + 1) >> 1]
+
+    every = np.arange(256, dtype=np.uint8)
+    got, last = M.pack_bases(every)
+    assert last == lut[255] and np.array_equal(got, image(lut[every], 0))
+    for n in (0, 1, 2, 3, 31, 32, 33, 63, 64, 65, 1000, 4097, (1 << 21) + 5, (3 << 20) + 1):
+        src = rng.choice(np.frombuffer(b"ACGTNacgtnRY-*\x00\xff", dtype=np.uint8), size=n)
+        for first in (0, 1, 6, 7):
+            prev = int(rng.integers(0, 5))
+            got, last = M.pack_bases(src, first_offset=first, prev_code=prev)
+            want = image(lut[src], first)
+            if first & 1 and n:
+                want = want.copy()
+                want[0] |= prev          # the base before the chunk shares its first byte
+            assert np.array_equal(got, want), (n, first)
+            assert last == (lut[src[-1]] if n else prev)
+    # two chunks of one segment, cut at an odd offset: the second rewrites the shared byte with both nibbles
+    src = rng.choice(np.frombuffer(b"ACGTN", dtype=np.uint8), size=2001)
+    a, la = M.pack_bases(src[:777])
+    b, _ = M.pack_bases(src[777:], first_offset=777, prev_code=la)
+    whole, _ = M.pack_bases(src)
+    assert np.array_equal(np.concatenate([a[:-1], b]), whole) and (a[-1] & 0xF) == (b[0] & 0xF)

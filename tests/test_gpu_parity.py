@@ -935,3 +935,38 @@ def test_batches_rich_in_n_overflow_the_listed_search_grid_and_run_again(small_d
     b.run_host(dirty, off, mp)
     assert_same_hits(b.download(), want_dirty)
     b.close()
+
+
+def test_host_batches_arrive_as_four_bit_codes_or_as_plain_bytes_with_the_same_hits(tricky, medium, monkeypatch):
+    """run_host packs the bases to 4-bit codes on the host (host_pack.cpp) and k_unpack expands them on the device when
+    the process has the CPUs for it (the GPU box has); MTSV_H2D_PLAIN=1 sends the bytes as they are and k_normalise maps
+    them there.  Reads of mixed length (odd offsets: chunks share a byte), lower case and junk bytes, in ordinary and in
+    page-locked memory, small input segments -- both forms against the oracle"""
+    ix, orc, reads = tricky
+    bases, off = helpers.reads_to_batch(reads)
+    ix.to_device(0)
+    want, _ = orc.bin_batch(bases, off, both_params()[1], threads=8)
+    hb = M.HostBuffer(len(bases))
+    hb.array[:] = bases
+    for plain in (False, True):
+        if plain:
+            monkeypatch.setenv("MTSV_H2D_PLAIN", "1")
+        else:
+            monkeypatch.delenv("MTSV_H2D_PLAIN", raising=False)
+        for src in (bases, hb.array):
+            b = M.Batch(ix, 0, 97, 1 << 14)
+            b.run_host(src, off)
+            assert_same_hits(b.download(), want)
+            b.close()
+        monkeypatch.setenv("MTSV_ARENA_BASES", "70000")        # several segments: the packed image starts anew in each
+        b = M.Batch(ix, 0, 97, 1 << 14)
+        b.run_host(hb.array, off)
+        assert_same_hits(b.download(), want)
+        b.close()
+        monkeypatch.delenv("MTSV_ARENA_BASES")
+    hb.close()
+    mix, mbases, moff = medium
+    mix.to_device(0)
+    whole = mix.bin_batch(mbases, moff, device=0)            # (packed when the box has the CPUs)
+    monkeypatch.setenv("MTSV_H2D_PLAIN", "1")
+    assert_same_hits(mix.bin_batch(mbases, moff, device=0), whole)

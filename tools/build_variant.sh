@@ -16,7 +16,7 @@ for f in ${file//,/ }; do
     python3 ../../tools/kernel_resources.py build/var/${f}_$name.remarks --guard > build/var/${f}_$name.resources.txt || { grep -v "spill   0 vgpr_spill   0" build/var/${f}_$name.resources.txt; exit 1; }
 done
 objs=""
-for o in mgindex builder capi dev_index k_seed k_coalesce k_verify batch gpu_builder; do
+for o in mgindex builder capi dev_index k_seed k_coalesce k_verify batch gpu_builder host_pack; do
     case ",$file," in *",$o,"*) objs="$objs build/var/${o}_$name.o";; *) objs="$objs build/$o.o";; esac
 done
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=gfx950 -o ../libmtsv_amd_$name.so $objs -lpthread
