@@ -360,14 +360,14 @@ def main():
         pass
 
     # The library packs the reads to 4-bit codes on the host before they cross PCIe when the process has the CPUs for it
-    # (host_pack.hpp: twelve threads at most, ten at least, else the plain bytes go).  It sees the affinity mask and the
+    # (host_pack.hpp: ten threads at most, nine at least, else the plain bytes go).  It sees the affinity mask and the
     # cgroup's quota, not the other ranks that share them: every rank gets its share.
     if world > 1 and "MTSV_PACK_THREADS" not in os.environ:
         hd = host_description()
         usable = hd["affinity_cpus"] * (world if affinity else 1)   # (the mask was narrowed to this GPU's node above)
         if hd.get("cgroup_cpu_quota"):
             usable = min(usable, int(round(hd["cgroup_cpu_quota"])))
-        os.environ["MTSV_PACK_THREADS"] = str(max(1, min(12, usable // world - 4)))
+        os.environ["MTSV_PACK_THREADS"] = str(max(1, min(10, usable // world - 4)))
 
     n_taxa, gis, seq_len, n_reads, read_len, desc = WORKLOADS[args.workload]
     if args.reads:

@@ -58,6 +58,8 @@ __attribute__((target("avx2"))) void pack_pairs_avx2(uint8_t* dst, const uint8_t
 #endif
 void pack_pairs(uint8_t* dst, const uint8_t* src, uint64_t n_pairs) {
 #if defined(__x86_64__)
+    // (a 512-bit variant -- one vpermi2b table look-up per 64 bases -- packs a third faster on one core and made the whole
+    //  step erratic on the GPU box's EPYC 9575F: 31.9 to 38.5 ms where this one holds 31.8-32.0)
     static const bool avx2 = __builtin_cpu_supports("avx2");
     if (avx2) return pack_pairs_avx2(dst, src, n_pairs);
 #endif
@@ -164,12 +166,13 @@ PackPool& pool() {
 }  // namespace
 
 // Threads that pack a chunk, the caller included: MTSV_PACK_THREADS, else what the process may use less the four threads
-// a host batch keeps busy besides (three lanes waiting on their streams, the feeder), twelve at most (measured on a
-// 16-CPU grant: 8 threads 37.1 ms per 10 M reads, 12 31.6, 16 32.6, 24 35.3; the plain transfer 36.1).
+// a host batch keeps busy besides (three lanes waiting on their streams, the feeder), ten at most (measured on a
+// 16-CPU grant, medians of ten steps: 8 threads 36.1 ms per 10 M reads, 10 31.9, 12 31.8, 16 32.6, 24 35.3; the plain
+// transfer 36.3).
 int pack_threads() {
     static const int n = [] {
         if (const char* e = getenv("MTSV_PACK_THREADS")) return std::max(1, std::min(64, atoi(e)));
-        return std::max(1, std::min(12, usable_cpus() - 4));
+        return std::max(1, std::min(10, usable_cpus() - 4));
     }();
     return n;
 }

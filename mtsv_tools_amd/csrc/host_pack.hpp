@@ -11,5 +11,5 @@ uint8_t pack_chunk(uint8_t* dst, const uint8_t* src, uint64_t a, uint64_t n, uin
 // threads pack_chunk uses, the caller included (MTSV_PACK_THREADS; else from the CPUs the process may use).  Fewer than
 // kPackWorthwhile of them are slower than the copy engine on the plain bytes: run_host then sends those.
 int pack_threads();
-constexpr int kPackWorthwhile = 10;
+constexpr int kPackWorthwhile = 9;
 }  // namespace mtsv
