@@ -1107,11 +1107,26 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
                 if (r + seg + cnt + 1 > h_off_cap) throw std::runtime_error("internal: more input segments than the offset array was sized for");
                 uint32_t ml = 0;
                 if (r == seg_first_read) ho[0] = 0;  // (else the previous chunk wrote this entry; a lane may be reading it)
-                for (uint64_t i = 1; i <= cnt; i++) {
-                    if (poff[i] < poff[i - 1]) throw std::runtime_error("arg: read_off is not ascending");
-                    const uint32_t v = (uint32_t)(b0 + (poff[i] - poff[0]) - seg_first_base);
-                    ml = std::max(ml, v - ho[i - 1]);
-                    ho[i] = v;
+                {
+                    // (on the packer's threads when it runs: a quarter of a million reads per chunk were 0.15 ms of the
+                    //  feeder's 0.56 per chunk)
+                    std::atomic<uint32_t> ml_all{0};
+                    std::atomic<bool> bad{false};
+                    auto narrow = [&](uint64_t i0, uint64_t i1) {  // entries i0 + 1 .. i1
+                        uint32_t m = 0;
+                        for (uint64_t i = i0 + 1; i <= i1; i++) {
+                            if (poff[i] < poff[i - 1]) bad.store(true);
+                            const uint32_t v = (uint32_t)(b0 + (poff[i] - poff[0]) - seg_first_base);
+                            m = std::max(m, (uint32_t)(poff[i] - poff[i - 1]));
+                            ho[i] = v;
+                        }
+                        uint32_t cur = ml_all.load();
+                        while (m > cur && !ml_all.compare_exchange_weak(cur, m)) {}
+                    };
+                    if (packed && cnt >= (1u << 16)) pack_pool_for(cnt, 1u << 14, narrow);
+                    else narrow(0, cnt);
+                    if (bad.load()) throw std::runtime_error("arg: read_off is not ascending");
+                    ml = ml_all.load();
                 }
                 const double t0 = now_s();
                 hipEvent_t ev = event_for(k);

@@ -4,6 +4,7 @@
 #include <cstdlib>
 #include <atomic>
 #include <condition_variable>
+#include <functional>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -68,7 +69,9 @@ void pack_pairs(uint8_t* dst, const uint8_t* src, uint64_t n_pairs) {
 // bases src[0, n) that lie at segment offsets [a, a + n) into packed bytes dst[0 ...) = bytes [a / 2, (a + n + 1) / 2) of the
 // segment; prev_code: the code of the base at offset a - 1 (when a is odd, it shares the first byte).  Returns the code of
 // the last base.
-// a few threads that live as long as the library: a chunk is cut into pieces of pairs, the caller takes pieces too
+// a few threads that live as long as the library: a job is cut into pieces, the caller takes pieces too.  Everything a
+// thread needs of a job lies in the job's own record, and run() does not return while a thread still holds it (jobs of
+// different piece sizes follow each other: a thread that came late to one must not mix its numbers with the next one's).
 class PackPool {
    public:
     explicit PackPool(int n) {
@@ -82,57 +85,71 @@ class PackPool {
         cv_.notify_all();
         for (auto& t : th_) t.join();
     }
-    int threads() const { return (int)th_.size(); }
-    // pack n_pairs pairs; returns when all of them are done (one job at a time: the caller holds job_mu_)
-    void run(uint8_t* dst, const uint8_t* src, uint64_t n_pairs, uint64_t piece) {
-        std::lock_guard<std::mutex> job(job_mu_);
+    // fn(p0, p1) over [0, n) in pieces; returns when all of them are done (one job at a time)
+    void run(uint64_t n, uint64_t piece, const std::function<void(uint64_t, uint64_t)>& fn) {
+        std::lock_guard<std::mutex> one(job_mu_);
+        Job j;
+        j.fn = &fn;
+        j.n = n;
+        j.piece = piece;
+        j.left = (n + piece - 1) / piece;
+        j.holders = 1;  // the caller
         {
             std::lock_guard<std::mutex> lk(mu_);
-            dst_ = dst;
-            src_ = src;
-            n_ = n_pairs;
-            piece_ = piece;
-            next_.store(0);
-            left_ = (n_pairs + piece - 1) / piece;
+            cur_ = &j;
             gen_++;
         }
         cv_.notify_all();
-        take();
+        take(j);
         std::unique_lock<std::mutex> lk(mu_);
-        done_.wait(lk, [&] { return left_ == 0; });
+        j.holders--;
+        done_.wait(lk, [&] { return j.left == 0 && j.holders == 0; });
+        cur_ = nullptr;
     }
 
    private:
-    void take() {
+    struct Job {
+        const std::function<void(uint64_t, uint64_t)>* fn = nullptr;
+        uint64_t n = 0, piece = 1;
+        std::atomic<uint64_t> next{0};
+        uint64_t left = 0;  // pieces not finished (mu_)
+        int holders = 0;    // threads that may still touch the record (mu_)
+    };
+    void take(Job& j) {
         for (;;) {
-            const uint64_t p0 = next_.fetch_add(piece_);
-            if (p0 >= n_) return;
-            const uint64_t p1 = std::min(n_, p0 + piece_);
-            pack_pairs(dst_ + p0, src_ + 2 * p0, p1 - p0);
+            const uint64_t p0 = j.next.fetch_add(j.piece);
+            if (p0 >= j.n) return;
+            (*j.fn)(p0, std::min(j.n, p0 + j.piece));
             std::lock_guard<std::mutex> lk(mu_);
-            if (--left_ == 0) done_.notify_all();
+            j.left--;
         }
     }
     void work() {
         uint64_t seen = 0;
         for (;;) {
+            Job* j;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                cv_.wait(lk, [&] { return stop_ || (cur_ && gen_ != seen); });
                 if (stop_) return;
                 seen = gen_;
+                j = cur_;
+                j->holders++;
             }
-            take();
+            take(*j);
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                j->holders--;
+                if (j->left == 0 && j->holders == 0) done_.notify_all();
+            }
         }
     }
     std::vector<std::thread> th_;
     std::mutex mu_, job_mu_;
     std::condition_variable cv_, done_;
     bool stop_ = false;
-    uint64_t gen_ = 0, left_ = 0, n_ = 0, piece_ = 1;
-    std::atomic<uint64_t> next_{0};
-    uint8_t* dst_ = nullptr;
-    const uint8_t* src_ = nullptr;
+    uint64_t gen_ = 0;
+    Job* cur_ = nullptr;
 };
 // CPUs this process may keep busy: its affinity mask, capped by the cgroup's CPU quota (v2 cpu.max, v1 cfs_quota_us)
 int usable_cpus() {
@@ -187,9 +204,18 @@ uint8_t pack_chunk(uint8_t* dst, const uint8_t* src, uint64_t a, uint64_t n, uin
     }
     const uint64_t n_pairs = (n - s) / 2;
     if (n_pairs < (1u << 18)) pack_pairs(d, src + s, n_pairs);  // (half a MiB of bases: not worth waking anybody)
-    else pool().run(d, src + s, n_pairs, 1u << 17);              // pieces of 256 KiB of bases
+    else {
+        const uint8_t* sp = src + s;
+        pool().run(n_pairs, 1u << 17, [d, sp](uint64_t p0, uint64_t p1) { pack_pairs(d + p0, sp + 2 * p0, p1 - p0); });  // pieces of 256 KiB of bases
+    }
     if ((n - s) & 1) d[n_pairs] = host_code(src[n - 1]);  // the last base alone in its byte (the next chunk completes it)
     return host_code(src[n - 1]);
+}
+
+
+void pack_pool_for(uint64_t n, uint64_t piece, const std::function<void(uint64_t, uint64_t)>& fn) {
+    if (n <= piece) fn(0, n);
+    else pool().run(n, piece, fn);
 }
 
 }  // namespace mtsv

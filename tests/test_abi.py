@@ -193,3 +193,37 @@ def test_pack_bases_is_the_normalisation_of_the_reference_in_four_bits():
     b, _ = M.pack_bases(src[777:], first_offset=777, prev_code=la)
     whole, _ = M.pack_bases(src)
     assert np.array_equal(np.concatenate([a[:-1], b]), whole) and (a[-1] & 0xF) == (b[0] & 0xF)
+
+
+def test_pack_pool_serves_concurrent_callers():
+    """the packer's thread pool is shared by every workspace of the process (a worker thread per device, several lanes):
+    three callers pack chunks of different sizes at once, every result checked"""
+    import threading
+    import numpy as np
+    import mtsv_tools_amd as M
+
+    lut = np.full(256, 4, dtype=np.uint8)
+    for k, ch in enumerate("ACGT"):
+        lut[ord(ch)] = lut[ord(ch.lower())] = k
+    errors = []
+
+    def caller(seed):
+        r = np.random.default_rng(seed)
+        try:
+            for _ in range(25):
+                n = int(r.integers(1 << 19, 5 << 19))
+                src = r.choice(np.frombuffer(b"ACGTNacgt", dtype=np.uint8), size=n)
+                got, _ = M.pack_bases(src)
+                c = lut[src]
+                if n & 1:
+                    c = np.append(c, 0)
+                assert np.array_equal(got, c[0::2] | (c[1::2] << 4))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    th = [threading.Thread(target=caller, args=(s,)) for s in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errors and not any(t.is_alive() for t in th)
