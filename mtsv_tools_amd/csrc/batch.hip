@@ -944,7 +944,16 @@ void Batch::run_host_parts(const HostPart* parts, int n_parts, const mtsv_params
     // The bases cross PCIe as 4-bit codes, packed on the host chunk by chunk into page-locked staging buffers while the
     // chunk before is on its way -- when the process has the CPUs for it (host_pack.hpp).  Otherwise, and with
     // MTSV_H2D_PLAIN=1: the bytes as they are (from page-locked memory in place) and k_normalise on the device.
-    const bool packed = !getenv("MTSV_H2D_PLAIN") && pack_threads() >= kPackWorthwhile;
+    // (one host batch at a time has the packer: a second one that runs beside it in this process -- another device of
+    //  mtsv_bin_batch_multi, another worker -- would wait for the pool chunk by chunk, and sends its bytes plain)
+    static std::atomic<int> host_runs{0};
+    struct HostRun {
+        std::atomic<int>& c;
+        const int mine;
+        explicit HostRun(std::atomic<int>& c_) : c(c_), mine(++c_) {}
+        ~HostRun() { c--; }
+    } host_run{host_runs};
+    const bool packed = !getenv("MTSV_H2D_PLAIN") && pack_threads() >= kPackWorthwhile && host_run.mine == 1;
     if ((packed || !direct) && !h_stage[0])
         for (auto& hs : h_stage) HIP_CHECK(hipHostMalloc((void**)&hs, kChunkMax + 64));
 
