@@ -721,6 +721,10 @@ def main():
         "step_ms_each": each_ms,
         "device_resident": resident,
         "host_input": "ordinary (pageable) memory" if args.pageable_input else "page-locked memory from mtsv_host_alloc",
+        "host_transfer": ({"form": "4-bit codes, packed on the host chunk by chunk (csrc/host_pack.cpp), expanded by k_unpack",
+                           "pack_threads": M.lib().mtsv_host_pack_threads()} if M.lib().mtsv_host_pack_threads()
+                          else {"form": "plain bytes (MTSV_H2D_PLAIN, or fewer than nine CPUs to pack with), k_normalise on the device",
+                                "pack_threads": 0}),
         "pageable_input": pageable,
         "config": {"workload": f"{args.workload}: {desc}", "reads_per_gpu_per_step": n_reads, "read_len": read_len,
                    "index_symbols": info["n"], "index_file_bytes": os.path.getsize(idx_path),

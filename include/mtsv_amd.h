@@ -247,6 +247,9 @@ void mtsv_free(void *p);
  * i / 2); prev_code is the code of the base before the first (it shares the first byte when first_offset is odd).
  * Returns the code of the last base. */
 uint8_t mtsv_pack_bases(uint8_t *dst, const uint8_t *src, uint64_t first_offset, uint64_t n, uint8_t prev_code);
+/* Host threads that pack the bases of a host batch in this process (the CPUs it may use less four, ten at most;
+ * MTSV_PACK_THREADS overrides); 0: the bytes go as they are (MTSV_H2D_PLAIN=1, or fewer than nine threads). */
+int mtsv_host_pack_threads(void);
 
 /* ---- synthetic workloads for bench.py / tests (not part of the drop-in) ---- */
 /* i.i.d. ACGT reference of n_taxa x gis_per_taxon sequences of seq_len, 5% of each overwritten by

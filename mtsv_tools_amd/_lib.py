@@ -66,7 +66,7 @@ EXPORTS = [
     "mtsv_free", "mtsv_synth_index", "mtsv_synth_reads", "mtsv_bin_batch_workspace_reads",
     "mtsv_bin_batch_multi", "mtsv_bin_batch_chunks", "mtsv_set_default_verify_mode",
     "mtsv_host_alloc", "mtsv_host_free", "mtsv_host_register", "mtsv_host_unregister",
-    "mtsv_batch_create_lanes", "mtsv_batch_reserve_host", "mtsv_pack_bases",
+    "mtsv_batch_create_lanes", "mtsv_batch_reserve_host", "mtsv_pack_bases", "mtsv_host_pack_threads",
 ]
 
 _lib = None

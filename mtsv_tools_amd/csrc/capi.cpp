@@ -678,6 +678,12 @@ int mtsv_synth_index(uint64_t seed, uint32_t n_taxa, uint32_t gis_per_taxon, uin
     })
 }
 
+int mtsv_host_pack_threads(void) {
+    if (getenv("MTSV_H2D_PLAIN")) return 0;
+    const int n = mtsv::pack_threads();
+    return n >= mtsv::kPackWorthwhile ? n : 0;
+}
+
 uint8_t mtsv_pack_bases(uint8_t* dst, const uint8_t* src, uint64_t first_offset, uint64_t n, uint8_t prev_code) {
     return mtsv::pack_chunk(dst, src, first_offset, n, prev_code);
 }
