@@ -288,9 +288,10 @@ class ParallelFastx {
         pool_.clear();
     }
 
-    // The mapping is only used to look for block boundaries (a few pages per block); block contents
-    // are pread() into a per-thread buffer: a copy out of the page cache, without one page fault per
-    // 4 KiB of input in a shared address space.
+    // A block is parsed where the file is mapped: one madvise(MADV_POPULATE_READ) maps its pages, and the parser reads the
+    // page cache's own pages.  (Until the end of r03 every block was copied out with pread first -- 5 GB/s per thread,
+    // more than half of a parser thread's time; page faults in one address space are no longer what they were when that
+    // was chosen: per-VMA locks.)  MTSV_INGEST_PREAD=1 keeps the copy.
     void worker() {
         std::vector<uint8_t> buf;
         for (;;) {
@@ -314,14 +315,25 @@ class ParallelFastx {
                 if (prepare) prepare(p->block);  // (a block with its storage already there, from the caller's stock)
             }
             const uint64_t s = bounds_[k], len = bounds_[k + 1] - s;
-            if (buf.size() < len) buf.resize(len);
+            const uint8_t* src;
             uint64_t got = 0;
-            while (got < len) {
-                ssize_t r = pread(fd_, buf.data() + got, len - got, (off_t)(s + got));
-                if (r <= 0) break;
-                got += (uint64_t)r;
+            if (from_map_) {  // parse where the page cache's pages are mapped (one madvise call maps the block's pages)
+                src = data_ + s;
+                const uint64_t a = s & ~4095ull;
+#ifdef MADV_POPULATE_READ
+                (void)madvise(const_cast<uint8_t*>(data_) + a, s + len - a, MADV_POPULATE_READ);
+#endif
+                got = len;
+            } else {
+                if (buf.size() < len) buf.resize(len);
+                while (got < len) {
+                    ssize_t r = pread(fd_, buf.data() + got, len - got, (off_t)(s + got));
+                    if (r <= 0) break;
+                    got += (uint64_t)r;
+                }
+                src = buf.data();
             }
-            p->ok = got == len && (fastq_ ? parse_fastq(buf.data(), len, p->block) : parse_fasta(buf.data(), len, k == 0, k + 1 == n_blocks_, p->block));
+            p->ok = got == len && (fastq_ ? parse_fastq(src, len, p->block) : parse_fasta(src, len, k == 0, k + 1 == n_blocks_, p->block));
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 done_[k] = std::move(p);
@@ -432,6 +444,7 @@ class ParallelFastx {
     }
 
     const uint8_t* data_ = nullptr;
+    bool from_map_ = getenv("MTSV_INGEST_PREAD") == nullptr;  // parse where the file is mapped (MTSV_INGEST_PREAD=1: copy the block out with pread first)
     int fd_ = -1;
     uint64_t size_ = 0;
     bool fastq_ = true;

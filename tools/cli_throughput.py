@@ -61,6 +61,9 @@ for br in ("65536", "131072", "262144"):
     run("/tmp/cli.fastq", ["--batch-reads", br])
 for wk in ("1", "2", "3"):
     run("/tmp/cli.fastq", env={"MTSV_CLI_WORKERS": wk})
+for _ in range(2):
+    run("/tmp/cli.fastq", env={"MTSV_INGEST_PREAD": "1"})   # blocks copied out of the page cache with pread before they are parsed
+    run("/tmp/cli.fastq")
 run("/tmp/cli.fastq", env={"MTSV_CLI_PACKED": "1"})     # the bases packed to 4-bit codes on the host before they cross PCIe
 run("/tmp/cli.fastq", env={"MTSV_CLI_COLD": "1"})       # workspaces not sized / warmed before the clock starts
 for gr in ("262144", "1048576"):
