@@ -635,13 +635,15 @@ int main(int argc, char** argv) {
     // One library call takes every batch that is waiting, up to kGroupReads reads (mtsv_batch_run_host_parts): the device
     // is several times faster on passes of a million reads than on a quarter of that (a pass costs ~2.5 ms before it does
     // any work), while the parser is fastest on blocks of ~80 MB.
-    uint64_t kGroupReads = std::max<uint64_t>(a.batch_reads, 512ull << 10);
+    uint64_t kGroupReads = std::max<uint64_t>(a.batch_reads, 1ull << 20);
     if (const char* e = getenv("MTSV_CLI_GROUP_READS")) kGroupReads = std::max<uint64_t>(a.batch_reads, strtoull(e, nullptr, 10));
     const size_t group_max = (size_t)std::min<uint64_t>(32, std::max<uint64_t>(1, kGroupReads / std::max<uint64_t>(a.batch_reads, 1)));
     // Several workers per --devices entry, a workspace of ONE lane each: a call is copy in -> kernels -> hits out, and
     // what overlaps on the device are the calls of different workers (tools/call_stream.py: one worker with the
     // default three lanes 165 M reads/s on megaread calls, three workers of one lane 229 M).
-    size_t workers_per_device = 2;
+    // (three workers on groups of 1 Mi reads: 0.210 s for 32 M reads twice over; two on 512 Ki: 0.225-0.245 -- since the
+    //  parser stopped copying its blocks the workers are what a run waits for)
+    size_t workers_per_device = 3;
     if (const char* e = getenv("MTSV_CLI_WORKERS")) workers_per_device = (size_t)std::max(1, std::min(8, atoi(e)));
     // (a small input is through before the extra workspaces have paid for themselves)
     uint64_t input_bytes = 0;
