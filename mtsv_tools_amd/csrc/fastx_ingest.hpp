@@ -334,6 +334,10 @@ class ParallelFastx {
                 src = buf.data();
             }
             p->ok = got == len && (fastq_ ? parse_fastq(src, len, p->block) : parse_fasta(src, len, k == 0, k + 1 == n_blocks_, p->block));
+            if (from_map_) {  // the block's pages leave the address space again: a 300 GB input must not become 300 GB of mapped pages
+                const uint64_t a = (s + 4095) & ~4095ull, e = (s + len) & ~4095ull;
+                if (e > a) (void)madvise(const_cast<uint8_t*>(data_) + a, e - a, MADV_DONTNEED);
+            }
             {
                 std::lock_guard<std::mutex> lk(mu_);
                 done_[k] = std::move(p);
