@@ -400,7 +400,8 @@ class ParallelFastx {
             if (e0 >= e) return false;  // header without a sequence line inside the block
             uint64_t p1 = e0 + 1, e1 = eol(d, p1, e);
             if (e1 >= e) return false;
-            uint64_t p2 = e1 + 1, e2 = eol(d, p2, e);
+            uint64_t p2 = e1 + 1;
+            uint64_t e2 = p2 + 1 < e && d[p2 + 1] == '\n' ? p2 + 1 : eol(d, p2, e);  // ("+" alone on its line, as a rule)
             if (e2 >= e) return false;
             uint64_t p3 = e2 + 1, e3 = eol(d, p3, e);  // the last line may end at e without '\n'
             uint64_t h_len = e0 - p, s_len = e1 - p1, q_len = e3 - p3;
